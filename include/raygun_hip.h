@@ -1,0 +1,162 @@
+/* libraygun_hip.so — C-ABI of the MI355X (gfx950) hot path of raygun.
+ *
+ * Every entry point replaces a torch/cuDNN (or affogato) call the reference issues on its hot
+ * path; the reference file:line each one stands in for is cited next to it (paths relative to
+ * /root/reference/src/raygun/).  Conventions:
+ *   - plain pointers + sizes only, no torch types; the caller owns every buffer (workspace too);
+ *   - all work is enqueued asynchronously on the hipStream_t passed in; no hidden syncs;
+ *   - return 0 on success, a negative rg_status otherwise; rg_last_error_string() explains it;
+ *   - never throws, never aborts; re-entrant across streams/devices (no global mutable state
+ *     except the thread-local error string).
+ *
+ * Tensor convention: activations are channels-last bf16, "NDHWC with padded lanes": logical shape
+ * (N,C,D,H,W), channel stride 1, every other stride a multiple of 8 elements, base 16-byte aligned.
+ * Lanes [C, lanes) of every voxel are zero (lanes = C rounded up to 8).  Strides are in elements.
+ */
+#ifndef RAYGUN_HIP_H
+#define RAYGUN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* rg_stream; /* == hipStream_t */
+
+enum rg_status {
+  RG_OK = 0,
+  RG_ERR_BAD_SHAPE = -1,
+  RG_ERR_UNSUPPORTED = -2,
+  RG_ERR_HIP = -3,
+  RG_ERR_WORKSPACE = -4
+};
+enum rg_dtype { RG_BF16 = 0, RG_F32 = 1, RG_U8 = 2, RG_I32 = 3, RG_U64 = 4, RG_F64 = 5 };
+enum rg_act { RG_ACT_NONE = 0, RG_ACT_RELU = 1, RG_ACT_LEAKY = 2, RG_ACT_SIGMOID = 3, RG_ACT_TANH = 4 };
+
+typedef struct {
+  void* ptr;
+  int32_t dtype; /* rg_dtype */
+  int32_t rank;  /* 5 for activations: (N,C,D,H,W) logical order */
+  int64_t sizes[6];
+  int64_t strides[6]; /* in elements */
+} rg_tensor;
+
+int rg_version(void);
+const char* rg_last_error_string(void);
+
+/* ---- layout conversion (torch .to(memory_format)/.float() around the nets: torch/predict/worker.py:101-110,146-149)
+ * src: any dtype in {bf16,f32,u8}, any strides.  dst: bf16 or f32, any strides.  dst_lanes >= C: channel lanes
+ * [C,dst_lanes) of dst are zero-filled (dst channel stride must be 1 when dst_lanes > C).
+ * y = x*scale + shift fuses the block-runner normalisation (worker.py:109-114). */
+int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, rg_stream s);
+
+/* ---- weight packing.  w is the fp32 master in torch layout:
+ *   transposed == 0 : Conv3d weight (Cout,Cin,KD,KH,KW)        [torch.nn.Conv3d, networks/UNet.py:58-69]
+ *   transposed == 1 : ConvTranspose3d weight (Cin,Cout,KD,KH,KW) [networks/ResNet.py:325-333]
+ * mode 0 (forward operand of a conv / dgrad operand of a convT): rows = dim0 ... see conv.hip.
+ * Packed layout: bf16 [rows16][ntaps][red32], rows16 = rows rounded up to 16, red32 = reduced channels rounded
+ * up to 32, zero filled.  `swap` selects which of the two channel dims is the row dim (0: dim0 rows, 1: dim1 rows).
+ * The tap subset is {k0 + kstep*j, j < ntap} per dim (parity classes of strided transposed convs). */
+typedef struct {
+  int32_t dim0, dim1, K[3];
+  int32_t swap;
+  int32_t k0[3], kstep[3], ntap[3];
+} rg_pack_params;
+int64_t rg_pack_weights_bytes(const rg_pack_params* p);
+int rg_pack_weights(const float* w, void* packed_bf16, const rg_pack_params* p, rg_stream s);
+
+/* ---- implicit-GEMM convolution engine (Conv3d fwd, Conv3d dgrad, ConvTranspose3d fwd/dgrad).
+ * Replaces torch.nn.Conv3d/ConvTranspose3d forward+backward-data as issued by ConvPass (networks/UNet.py:58-69),
+ * ResnetGenerator3D (networks/ResNet.py:283,291-298,325-338), ResnetBlock3D (:407,416) and
+ * NLayerDiscriminator3D (networks/NLayerDiscriminator.py:136-176).
+ * rows form a grid (N,RD,RH,RW); row r and tap k read x at  r*rstride + tbase + tstep*k  (zero outside the volume)
+ * and write y at r*ostride + ooffset.  y = act(sum + bias). */
+typedef struct {
+  int32_t R[3];       /* row grid per sample */
+  int32_t T[3];       /* taps per dim */
+  int32_t rstride[3]; /* row -> input coordinate stride */
+  int32_t tbase[3], tstep[3];
+  int32_t ostride[3], ooffset[3];
+  int32_t cout;       /* real output channels */
+  int32_t act;        /* rg_act, fused epilogue */
+  float slope;        /* LeakyReLU slope */
+} rg_conv_params;
+int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
+                    const rg_conv_params* p, rg_stream s);
+
+/* ---- weight gradient.  dW[a][b][tap] = sum_rows g[row][a] * x[row*rstride + tbase + tstep*tap][b]
+ * (torch's conv backward-weight for the layers above).  Two steps: partial sums over row splits into the
+ * caller's fp32 workspace, then a deterministic reduction that also transposes into torch's (a,b,KD,KH,KW) layout.
+ * `accumulate` != 0 adds into dw instead of overwriting. */
+int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_tensor* x, const rg_conv_params* p, int32_t* nsplit);
+int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int accumulate,
+                    void* workspace, size_t ws_bytes, rg_stream s);
+
+/* ---- activation backward + bias gradient: g = gy * act'(y);  db[c] = sum_voxels g  (fp32, may be NULL).
+ * Replaces autograd of ReLU/LeakyReLU/Sigmoid after a conv (UNet.py:90-91, NLayerDiscriminator.py:138,156,173). */
+int rg_act_bwd_bias(const rg_tensor* gy, const rg_tensor* y, const rg_tensor* g, float* db, int act, float slope,
+                    void* workspace, size_t ws_bytes, rg_stream s);
+int64_t rg_act_bwd_bias_workspace_bytes(const rg_tensor* gy);
+
+/* ---- MaxPool3d k=s=factor, floor mode (MaxDownsample, networks/UNet.py:209-228). bwd recomputes the arg-max
+ * (first maximum in d,h,w scan order, torch's tie rule) and writes the full gx (zeros elsewhere). */
+int rg_maxpool3d_fwd(const rg_tensor* x, const rg_tensor* y, const int32_t factor[3], rg_stream s);
+int rg_maxpool3d_bwd(const rg_tensor* x, const rg_tensor* gy, const rg_tensor* gx, const int32_t factor[3], rg_stream s);
+
+/* ---- nearest upsample + centre crop + channel concat (Upsample.forward, networks/UNet.py:338-351):
+ * out[:, :Cf] = crop(f, off_f) ; out[:, Cf:] = crop(upsample(g, factor), off_g).
+ * bwd: gf = zero-embedded crop of gout[:, :Cf] ; gg = factor^3 sum-pool of gout[:, Cf:] over the cropped window. */
+int rg_upcat_fwd(const rg_tensor* f, const rg_tensor* g, const rg_tensor* out, const int32_t factor[3],
+                 const int32_t off_f[3], const int32_t off_g[3], rg_stream s);
+int rg_upcat_bwd(const rg_tensor* gout, const rg_tensor* gf, const rg_tensor* gg, const int32_t factor[3],
+                 const int32_t off_f[3], const int32_t off_g[3], rg_stream s);
+
+/* ---- InstanceNorm3d(affine=False, track_running_stats=False, eps) (+activation, +residual add)
+ * (networks/ResNet.py:284-285,299-300,408-409,417; NLayerDiscriminator.py:154-155; systems/BaseSystem.py:193-199).
+ * stats: float2 (mean, rstd) per (n,c).  apply: y = act((x-mean)*rstd) [+ res].  pad > 0 writes y reflect-padded
+ * by `pad` voxels per side (fuses the following ReflectionPad3d, ResNet.py:270,392). */
+int64_t rg_instnorm_workspace_bytes(const rg_tensor* x);
+int rg_instnorm_stats(const rg_tensor* x, float* mean_rstd, float eps, void* workspace, size_t ws_bytes, rg_stream s);
+int rg_instnorm_apply(const rg_tensor* x, const float* mean_rstd, const rg_tensor* res, const rg_tensor* y,
+                      int act, float slope, rg_stream s);
+/* gx = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = gy*act'(y).  y may be NULL when act == none. */
+int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const rg_tensor* y, const rg_tensor* gy,
+                    const rg_tensor* gx, int act, float slope, void* workspace, size_t ws_bytes, rg_stream s);
+
+/* ---- ReflectionPad3d / zero pad (ResNet.py:270,337,392): y = pad(x); bwd folds gy back onto gx. mode 0 zero, 1 reflect. */
+int rg_pad3d_fwd(const rg_tensor* x, const rg_tensor* y, const int32_t pad[3], int mode, rg_stream s);
+int rg_pad3d_bwd(const rg_tensor* gy, const rg_tensor* gx, const int32_t pad[3], int mode, rg_stream s);
+
+/* ---- residual add  y = a + b  (ResnetBlock3D.forward, ResNet.py:436-443) */
+int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream s);
+
+/* ---- losses: value (fp32 scalar in out[0]) and gradient wrt pred in one pass.
+ * kind 0: mean((p-t)^2) vs constant target  (GANLoss lsgan, losses/GANLoss.py:24-25,56-58)
+ * kind 1: SmoothL1(beta=1) mean vs tensor t  (LinkCycleLoss.py:22,99-106)
+ * kind 2: weighted MSE of WeightedMSELoss_MTLSD._calc_loss (losses/WeightedMSELoss_MTLSD.py:11-25):
+ *         out[0]=sum w*(p-t)^2, out[1]=count(w>0), out[2]=count(scaled!=0); grad is the un-normalised 2*w*(p-t). */
+int rg_loss_fwd_bwd(int kind, const rg_tensor* pred, const rg_tensor* target, const rg_tensor* weight, float const_target,
+                    float grad_scale, const rg_tensor* grad, float* out, rg_stream s);
+
+/* ---- fused Adam over one flat fp32 parameter (torch.optim.Adam semantics, optimizers/utils.py:4-9) */
+int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, float grad_scale, rg_stream s);
+
+/* ---- mutex watershed (affogato.segmentation.compute_mws_segmentation, called at segment.py:197-199) */
+typedef struct {
+  int32_t shape[3];
+  int32_t n_offsets, n_attractive;
+  int32_t strides[3];     /* sub-sampling stride of repulsive edges */
+  int32_t randomize_strides; /* must be 0 */
+} rg_mws_params;
+int64_t rg_mws_workspace_bytes(const rg_mws_params* p);
+/* affs: float32 (n_offsets,Z,Y,X) already in "edge weight" form (segment.py:191-194); offsets int32 (n_offsets,3);
+ * mask: uint8 (Z,Y,X) or NULL; labels: uint64 (Z,Y,X). */
+int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels,
+                   const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+// Shared device/host helpers for libraygun_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/raygun_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = 16 B
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // 4 bf16 = 8 B
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+#define RG_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------
+void rg_set_error(const char* fmt, ...);
+#define RG_FAIL(code, ...) do { rg_set_error(__VA_ARGS__); return (code); } while (0)
+#define RG_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+  rg_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return RG_ERR_HIP; } } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even; NaN stays NaN) --------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+  switch (act) {
+    case RG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case RG_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case RG_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case RG_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative expressed through the OUTPUT y of the activation
+__device__ __forceinline__ float act_bwd_from_y(float y, int act, float slope) {
+  switch (act) {
+    case RG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case RG_ACT_LEAKY: return y > 0.f ? 1.f : slope;
+    case RG_ACT_SIGMOID: return y * (1.f - y);
+    case RG_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// ---- tensor views ----------------------------------------------------------
+struct CL5 {  // channels-last 5-D activation view
+  bf16_t* p;
+  int N, C, D, H, W;
+  int lanes;            // readable/writable channel lanes (multiple of 8, >= C)
+  long sn, sd, sh, sw;  // element strides
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Validates the activation convention and fills a CL5.  `lanes` = C rounded up to 8.
+static inline int rg_as_cl5(const rg_tensor* t, CL5* o, const char* name) {
+  if (!t || !t->ptr) { rg_set_error("%s: null tensor", name); return RG_ERR_BAD_SHAPE; }
+  if (t->dtype != RG_BF16 || t->rank != 5) { rg_set_error("%s: expected bf16 rank-5 (N,C,D,H,W)", name); return RG_ERR_BAD_SHAPE; }
+  if (t->strides[1] != 1 && t->sizes[1] != 1) { rg_set_error("%s: channel stride must be 1 (channels-last)", name); return RG_ERR_BAD_SHAPE; }
+  o->p = (bf16_t*)t->ptr;
+  o->N = (int)t->sizes[0]; o->C = (int)t->sizes[1]; o->D = (int)t->sizes[2]; o->H = (int)t->sizes[3]; o->W = (int)t->sizes[4];
+  o->sn = t->strides[0]; o->sd = t->strides[2]; o->sh = t->strides[3]; o->sw = t->strides[4];
+  o->lanes = round_up(o->C, 8);
+  if (o->sw < o->lanes || (o->sw % 8) || (o->sh % 8) || (o->sd % 8) || (o->sn % 8) || (((uintptr_t)t->ptr) & 15)) {
+    rg_set_error("%s: strides must be multiples of 8 elements with W-stride >= padded lanes (C=%d sw=%ld) and base 16B aligned", name, o->C, o->sw);
+    return RG_ERR_BAD_SHAPE;
+  }
+  if (o->N <= 0 || o->C <= 0 || o->D <= 0 || o->H <= 0 || o->W <= 0) { rg_set_error("%s: empty tensor", name); return RG_ERR_BAD_SHAPE; }
+  return RG_OK;
+}

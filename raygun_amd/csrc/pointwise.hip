@@ -1,0 +1,444 @@
+// HBM-bound kernels of the hot path: layout conversion, weight packing, activation backward +
+// bias gradient, max-pool, nearest-upsample+crop+concat, residual add, losses, Adam.
+// All of them move 16 bytes (8 bf16 channel lanes) per thread-access on channels-last data.
+#include "common.h"
+#include <stdarg.h>
+
+// ---------------------------------------------------------------------------- error string / version
+static thread_local char g_err[512] = "";
+void rg_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* rg_last_error_string(void) { return g_err; }
+extern "C" int rg_version(void) { return 100; }
+
+static inline int grid_for(long n, int block = 256, int cap = 1 << 20) {
+  long g = (n + block - 1) / block; if (g > cap) g = cap; if (g < 1) g = 1; return (int)g;
+}
+
+// ---------------------------------------------------------------------------- copy / convert
+struct AnyT { void* p; int dtype; long s[5]; };  // strides for (n,c,d,h,w)
+
+__device__ __forceinline__ float load_any(const AnyT& t, long off) {
+  switch (t.dtype) {
+    case RG_F32: return ((const float*)t.p)[off];
+    case RG_U8: return (float)((const unsigned char*)t.p)[off];
+    default: return bf2f(((const bf16_t*)t.p)[off]);
+  }
+}
+__global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int H, int W, int lanes, float scale, float shift) {
+  const int G8 = (lanes + 7) / 8;
+  const long nvox = (long)N * D * H * W, total = nvox * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i % nvox; const int grp = (int)(i / nvox);
+    long t = v;
+    const int w = (int)(t % W); t /= W; const int h = (int)(t % H); t /= H; const int d = (int)(t % D); const int n = (int)(t / D);
+    const long so = n * src.s[0] + d * src.s[2] + h * src.s[3] + w * src.s[4];
+    const long dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = grp * 8 + k;
+      if (c >= lanes) break;
+      const float val = c < C ? load_any(src, so + c * src.s[1]) * scale + shift : 0.f;
+      if (dst.dtype == RG_F32) ((float*)dst.p)[dof + c * dst.s[1]] = val;
+      else ((bf16_t*)dst.p)[dof + c * dst.s[1]] = f2bf(val);
+    }
+  }
+}
+
+extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, rg_stream s) {
+  if (!src || !dst || !src->ptr || !dst->ptr) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: null tensor");
+  if (src->rank != 5 || dst->rank != 5) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: rank-5 tensors expected");
+  for (int i = 0; i < 5; ++i) if (src->sizes[i] != dst->sizes[i]) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: shape mismatch on dim %d", i);
+  if (dst->dtype != RG_BF16 && dst->dtype != RG_F32) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: dst must be bf16 or f32");
+  if (src->dtype != RG_BF16 && src->dtype != RG_F32 && src->dtype != RG_U8) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: src dtype");
+  const int C = (int)src->sizes[1];
+  if (dst_lanes < C) dst_lanes = C;
+  if (dst_lanes > C && dst->strides[1] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: padded lanes need channel stride 1");
+  AnyT a, b;
+  a.p = src->ptr; a.dtype = src->dtype; b.p = dst->ptr; b.dtype = dst->dtype;
+  for (int i = 0; i < 5; ++i) { a.s[i] = src->strides[i]; b.s[i] = dst->strides[i]; }
+  const long total = (long)src->sizes[0] * src->sizes[2] * src->sizes[3] * src->sizes[4] * ((dst_lanes + 7) / 8);
+  if (total == 0) return RG_OK;
+  hipLaunchKernelGGL(copy_convert_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, a, b, (int)src->sizes[0], C,
+                     (int)src->sizes[2], (int)src->sizes[3], (int)src->sizes[4], dst_lanes, scale, shift);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- weight packing
+__global__ void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
+  const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2];
+  const long total = (long)rows16 * ntap * red32;
+  const long kvol = (long)p.K[0] * p.K[1] * p.K[2];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % red32); long t = i / red32;
+    const int tap = (int)(t % ntap); const int r = (int)(t / ntap);
+    float v = 0.f;
+    if (r < rows && k < red) {
+      const int jw = tap % p.ntap[2], jh = (tap / p.ntap[2]) % p.ntap[1], jd = tap / (p.ntap[2] * p.ntap[1]);
+      const int kd = p.k0[0] + p.kstep[0] * jd, kh = p.k0[1] + p.kstep[1] * jh, kw = p.k0[2] + p.kstep[2] * jw;
+      const long kidx = ((long)kd * p.K[1] + kh) * p.K[2] + kw;
+      const long d0 = p.swap ? k : r, d1 = p.swap ? r : k;
+      v = w[(d0 * p.dim1 + d1) * kvol + kidx];
+    }
+    out[i] = f2bf(v);
+  }
+}
+static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
+  if (!p || p->dim0 <= 0 || p->dim1 <= 0) return -1;
+  for (int d = 0; d < 3; ++d) {
+    if (p->K[d] <= 0 || p->ntap[d] <= 0 || p->k0[d] < 0 || p->kstep[d] <= 0) return -1;
+    if (p->k0[d] + p->kstep[d] * (p->ntap[d] - 1) >= p->K[d]) return -1;
+  }
+  *rows = p->swap ? p->dim1 : p->dim0; *red = p->swap ? p->dim0 : p->dim1;
+  return 0;
+}
+extern "C" int64_t rg_pack_weights_bytes(const rg_pack_params* p) {
+  int rows, red;
+  if (pack_dims(p, &rows, &red)) return -1;
+  return (int64_t)round_up(rows, 16) * p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, 32) * 2;
+}
+extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_params* p, rg_stream s) {
+  int rows, red;
+  if (!w || !packed || pack_dims(p, &rows, &red)) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: bad params");
+  const int rows16 = round_up(rows, 16), red32 = round_up(red, 32);
+  const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- activation backward + bias grad
+// block (GX, GY): x = 8-lane channel group, y = voxel sub-index.  partial[blockIdx.x][lanes] fp32.
+__global__ void act_bwd_bias_kernel(CL5 gy, CL5 y, CL5 g, float* partial, int act, float slope, int vox_per_block, int has_y) {
+  extern __shared__ float red[];  // [GY][GX*8]
+  const int GX = blockDim.x, GY = blockDim.y;
+  const int grp = blockIdx.y * GX + threadIdx.x;
+  const long nvox = (long)gy.N * gy.D * gy.H * gy.W;
+  const long v0 = (long)blockIdx.x * vox_per_block;
+  long v1 = v0 + vox_per_block; if (v1 > nvox) v1 = nvox;
+  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (grp * 8 < gy.lanes) {
+    for (long v = v0 + threadIdx.y; v < v1; v += GY) {
+      long t = v;
+      const int w = (int)(t % gy.W); t /= gy.W; const int h = (int)(t % gy.H); t /= gy.H; const int d = (int)(t % gy.D); const int n = (int)(t / gy.D);
+      const bf16x8 a = *(const bf16x8*)(gy.p + n * gy.sn + d * gy.sd + h * gy.sh + w * gy.sw + grp * 8);
+      bf16x8 o;
+      if (has_y) {
+        const bf16x8 yy = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float gv = bf2f((bf16_t)a[k]) * act_bwd_from_y(bf2f((bf16_t)yy[k]), act, slope);
+          const bf16_t r = f2bf(gv); o[k] = (short)r; sum[k] += bf2f(r);
+        }
+      } else {
+        o = a;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] += bf2f((bf16_t)a[k]);
+      }
+      if (g.p) *(bf16x8*)(g.p + n * g.sn + d * g.sd + h * g.sh + w * g.sw + grp * 8) = o;
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[(threadIdx.y * GX + threadIdx.x) * 8 + k] = sum[k];
+  __syncthreads();
+  if (threadIdx.y == 0 && grp * 8 < gy.lanes) {
+    for (int yy = 1; yy < GY; ++yy)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum[k] += red[(yy * GX + threadIdx.x) * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * gy.lanes + grp * 8 + k] = sum[k];
+  }
+}
+__global__ void reduce_partials_kernel(const float* partial, float* out, int nblk, int lanes, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(long)b * lanes + c];
+  out[c] = s;
+}
+static void abb_plan(const CL5& t, int* gx, int* gy, int* vpb, int* nblk) {
+  const int G8 = t.lanes / 8;
+  int x = 1; while (x < G8 && x < 32) x <<= 1;
+  *gx = x; *gy = 256 / x;
+  const long nvox = (long)t.N * t.D * t.H * t.W;
+  long want = 1024; long v = (nvox + want - 1) / want; if (v < *gy * 4) v = *gy * 4;
+  *vpb = (int)v; *nblk = (int)((nvox + v - 1) / v);
+}
+extern "C" int64_t rg_act_bwd_bias_workspace_bytes(const rg_tensor* gy) {
+  CL5 t; if (rg_as_cl5(gy, &t, "act_bwd.gy")) return -1;
+  int gx, gyy, vpb, nblk; abb_plan(t, &gx, &gyy, &vpb, &nblk);
+  return (int64_t)nblk * t.lanes * 4;
+}
+extern "C" int rg_act_bwd_bias(const rg_tensor* gy, const rg_tensor* y, const rg_tensor* g, float* db, int act, float slope,
+                               void* workspace, size_t ws_bytes, rg_stream s) {
+  CL5 GY, Y, G; int rc;
+  if ((rc = rg_as_cl5(gy, &GY, "act_bwd.gy"))) return rc;
+  const int has_y = (act != RG_ACT_NONE);
+  memset(&Y, 0, sizeof(Y)); memset(&G, 0, sizeof(G));
+  if (has_y) { if ((rc = rg_as_cl5(y, &Y, "act_bwd.y"))) return rc;
+    if (Y.N != GY.N || Y.C != GY.C || Y.D != GY.D || Y.H != GY.H || Y.W != GY.W) RG_FAIL(RG_ERR_BAD_SHAPE, "act_bwd: y/gy shape mismatch"); }
+  if (g && g->ptr) { if ((rc = rg_as_cl5(g, &G, "act_bwd.g"))) return rc;
+    if (G.N != GY.N || G.C != GY.C || G.D != GY.D || G.H != GY.H || G.W != GY.W) RG_FAIL(RG_ERR_BAD_SHAPE, "act_bwd: g/gy shape mismatch"); }
+  int gx, gyy, vpb, nblk; abb_plan(GY, &gx, &gyy, &vpb, &nblk);
+  float* partial = nullptr;
+  if (db) {
+    const size_t need = (size_t)nblk * GY.lanes * 4;
+    if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "act_bwd: workspace %zu < %zu", ws_bytes, need);
+    partial = (float*)workspace;
+  }
+  dim3 grid(nblk, (GY.lanes / 8 + gx - 1) / gx), block(gx, gyy);
+  hipLaunchKernelGGL(act_bwd_bias_kernel, grid, block, 256 * 8 * sizeof(float), (hipStream_t)s, GY, Y, G, partial, act, slope, vpb, has_y);
+  RG_CHECK_LAUNCH();
+  if (db) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((GY.C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, db, nblk, GY.lanes, GY.C);
+    RG_CHECK_LAUNCH();
+  }
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- max pool
+__global__ void maxpool_fwd_kernel(CL5 x, CL5 y, int fd, int fh, int fw) {
+  const int G8 = y.lanes / 8;
+  const long total = (long)y.N * y.D * y.H * y.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+    for (int a = 0; a < fd; ++a) for (int b = 0; b < fh; ++b) for (int c = 0; c < fw; ++c) {
+      const bf16x8 v = *(const bf16x8*)(x.p + n * x.sn + (long)(d * fd + a) * x.sd + (long)(h * fh + b) * x.sh + (long)(w * fw + c) * x.sw + grp * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float f = bf2f((bf16_t)v[k]); if (f > m[k] || f != f) m[k] = f; }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (short)f2bf(m[k]);
+    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8) = o;
+  }
+}
+__global__ void maxpool_bwd_kernel(CL5 x, CL5 gy, CL5 gx, int fd, int fh, int fw) {
+  const int G8 = gy.lanes / 8;
+  const long total = (long)gy.N * gy.D * gy.H * gy.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % gy.W); t /= gy.W; const int h = (int)(t % gy.H); t /= gy.H; const int d = (int)(t % gy.D); const int n = (int)(t / gy.D);
+    float m[8]; int arg[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; arg[k] = 0; }
+    int idx = 0;
+    for (int a = 0; a < fd; ++a) for (int b = 0; b < fh; ++b) for (int c = 0; c < fw; ++c, ++idx) {
+      const bf16x8 v = *(const bf16x8*)(x.p + n * x.sn + (long)(d * fd + a) * x.sd + (long)(h * fh + b) * x.sh + (long)(w * fw + c) * x.sw + grp * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float f = bf2f((bf16_t)v[k]); if (f > m[k] || f != f) { m[k] = f; arg[k] = idx; } }
+    }
+    const bf16x8 gv = *(const bf16x8*)(gy.p + n * gy.sn + d * gy.sd + h * gy.sh + w * gy.sw + grp * 8);
+    idx = 0;
+    for (int a = 0; a < fd; ++a) for (int b = 0; b < fh; ++b) for (int c = 0; c < fw; ++c, ++idx) {
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (arg[k] == idx) ? gv[k] : (short)0;
+      *(bf16x8*)(gx.p + n * gx.sn + (long)(d * fd + a) * gx.sd + (long)(h * fh + b) * gx.sh + (long)(w * fw + c) * gx.sw + grp * 8) = o;
+    }
+  }
+}
+// zero every voxel of t outside the box [0,bd)x[0,bh)x[0,bw) (used for floor-cropped borders)
+__global__ void zero_outside_kernel(CL5 t, int bd, int bh, int bw) {
+  const int G8 = t.lanes / 8;
+  const long total = (long)t.N * t.D * t.H * t.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long q = i / G8;
+    const int w = (int)(q % t.W); q /= t.W; const int h = (int)(q % t.H); q /= t.H; const int d = (int)(q % t.D); const int n = (int)(q / t.D);
+    if (d < bd && h < bh && w < bw) continue;
+    *(bf16x8*)(t.p + n * t.sn + d * t.sd + h * t.sh + w * t.sw + grp * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+static int pool_check(const CL5& X, const CL5& Y, const int32_t f[3], const char* what) {
+  if (f[0] <= 0 || f[1] <= 0 || f[2] <= 0) RG_FAIL(RG_ERR_BAD_SHAPE, "%s: bad factor", what);
+  if (Y.N != X.N || Y.C != X.C || Y.D != X.D / f[0] || Y.H != X.H / f[1] || Y.W != X.W / f[2])
+    RG_FAIL(RG_ERR_BAD_SHAPE, "%s: output must be floor(input/factor): in (%d,%d,%d) out (%d,%d,%d)", what, X.D, X.H, X.W, Y.D, Y.H, Y.W);
+  return RG_OK;
+}
+extern "C" int rg_maxpool3d_fwd(const rg_tensor* x, const rg_tensor* y, const int32_t factor[3], rg_stream s) {
+  CL5 X, Y; int rc;
+  if ((rc = rg_as_cl5(x, &X, "maxpool.x")) || (rc = rg_as_cl5(y, &Y, "maxpool.y")) || (rc = pool_check(X, Y, factor, "maxpool_fwd"))) return rc;
+  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, factor[0], factor[1], factor[2]);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_maxpool3d_bwd(const rg_tensor* x, const rg_tensor* gy, const rg_tensor* gx, const int32_t factor[3], rg_stream s) {
+  CL5 X, GY, GX; int rc;
+  if ((rc = rg_as_cl5(x, &X, "maxpool.x")) || (rc = rg_as_cl5(gy, &GY, "maxpool.gy")) || (rc = rg_as_cl5(gx, &GX, "maxpool.gx")) ||
+      (rc = pool_check(X, GY, factor, "maxpool_bwd"))) return rc;
+  if (GX.N != X.N || GX.C != X.C || GX.D != X.D || GX.H != X.H || GX.W != X.W) RG_FAIL(RG_ERR_BAD_SHAPE, "maxpool_bwd: gx shape != x shape");
+  if (X.D % factor[0] || X.H % factor[1] || X.W % factor[2]) {
+    const long tot = (long)GX.N * GX.D * GX.H * GX.W * (GX.lanes / 8);
+    hipLaunchKernelGGL(zero_outside_kernel, dim3(grid_for(tot)), dim3(256), 0, (hipStream_t)s, GX, GY.D * factor[0], GY.H * factor[1], GY.W * factor[2]);
+    RG_CHECK_LAUNCH();
+  }
+  const long total = (long)GY.N * GY.D * GY.H * GY.W * (GY.lanes / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, GY, GX, factor[0], factor[1], factor[2]);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- upsample + crop + concat
+struct UpcatGeom { int fd, fh, fw, ofd, ofh, ofw, ogd, ogh, ogw; };
+__global__ void upcat_fwd_kernel(CL5 f, CL5 g, CL5 o, UpcatGeom q) {
+  const int G8 = o.lanes / 8;
+  const long total = (long)o.N * o.D * o.H * o.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % o.W); t /= o.W; const int h = (int)(t % o.H); t /= o.H; const int d = (int)(t % o.D); const int n = (int)(t / o.D);
+    const bf16_t* fp = f.p + n * f.sn + (long)(d + q.ofd) * f.sd + (long)(h + q.ofh) * f.sh + (long)(w + q.ofw) * f.sw;
+    const bf16_t* gp = g.p + n * g.sn + (long)((d + q.ogd) / q.fd) * g.sd + (long)((h + q.ogh) / q.fh) * g.sh + (long)((w + q.ogw) / q.fw) * g.sw;
+    bf16x8 v;
+    const int c0 = grp * 8;
+    if (c0 + 8 <= f.C) v = *(const bf16x8*)(fp + c0);
+    else if (c0 >= f.C && ((c0 - f.C) & 7) == 0 && c0 - f.C + 8 <= g.lanes) v = *(const bf16x8*)(gp + (c0 - f.C));
+    else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        v[k] = c < f.C ? (short)fp[c] : (c < o.C ? (short)gp[c - f.C] : (short)0);
+      }
+    }
+    *(bf16x8*)(o.p + n * o.sn + d * o.sd + h * o.sh + w * o.sw + c0) = v;
+  }
+}
+// gf: full skip-sized gradient (zero outside the crop window)
+__global__ void upcat_bwd_f_kernel(CL5 go, CL5 gf, UpcatGeom q) {
+  const int G8 = gf.lanes / 8;
+  const long total = (long)gf.N * gf.D * gf.H * gf.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % gf.W); t /= gf.W; const int h = (int)(t % gf.H); t /= gf.H; const int d = (int)(t % gf.D); const int n = (int)(t / gf.D);
+    const int od = d - q.ofd, oh = h - q.ofh, ow = w - q.ofw;
+    bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)od < (unsigned)go.D && (unsigned)oh < (unsigned)go.H && (unsigned)ow < (unsigned)go.W) {
+      const bf16_t* p = go.p + n * go.sn + (long)od * go.sd + (long)oh * go.sh + (long)ow * go.sw + grp * 8;
+      if (grp * 8 + 8 <= gf.C) v = *(const bf16x8*)p;
+      else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (grp * 8 + k < gf.C) ? (short)p[k] : (short)0;
+      }
+    }
+    *(bf16x8*)(gf.p + n * gf.sn + d * gf.sd + h * gf.sh + w * gf.sw + grp * 8) = v;
+  }
+}
+// gg: sum over the factor^3 upsampled positions that survive the crop
+__global__ void upcat_bwd_g_kernel(CL5 go, CL5 gg, int Cf, UpcatGeom q) {
+  const int G8 = gg.lanes / 8;
+  const long total = (long)gg.N * gg.D * gg.H * gg.W * G8;
+  const bool vec = (Cf & 7) == 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % gg.W); t /= gg.W; const int h = (int)(t % gg.H); t /= gg.H; const int d = (int)(t % gg.D); const int n = (int)(t / gg.D);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < q.fd; ++a) { const int od = d * q.fd + a - q.ogd; if ((unsigned)od >= (unsigned)go.D) continue;
+      for (int b = 0; b < q.fh; ++b) { const int oh = h * q.fh + b - q.ogh; if ((unsigned)oh >= (unsigned)go.H) continue;
+        for (int c = 0; c < q.fw; ++c) { const int ow = w * q.fw + c - q.ogw; if ((unsigned)ow >= (unsigned)go.W) continue;
+          const bf16_t* p = go.p + n * go.sn + (long)od * go.sd + (long)oh * go.sh + (long)ow * go.sw + Cf + grp * 8;
+          if (vec) { const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += bf2f((bf16_t)v[k]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (grp * 8 + k < gg.C) acc[k] += bf2f(p[k]);
+          }
+        } } }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (grp * 8 + k < gg.C) ? (short)f2bf(acc[k]) : (short)0;
+    *(bf16x8*)(gg.p + n * gg.sn + d * gg.sd + h * gg.sh + w * gg.sw + grp * 8) = o;
+  }
+}
+static int upcat_check(const CL5& F, const CL5& G, const CL5& O, const int32_t* fac, const int32_t* of, const int32_t* og, UpcatGeom* q) {
+  if (O.C != F.C + G.C || O.N != F.N || O.N != G.N) RG_FAIL(RG_ERR_BAD_SHAPE, "upcat: channels %d != %d + %d", O.C, F.C, G.C);
+  const int Od[3] = {O.D, O.H, O.W}, Fd[3] = {F.D, F.H, F.W}, Gd[3] = {G.D, G.H, G.W};
+  for (int d = 0; d < 3; ++d) {
+    if (fac[d] <= 0 || of[d] < 0 || og[d] < 0) RG_FAIL(RG_ERR_BAD_SHAPE, "upcat: bad factor/offset");
+    if (of[d] + Od[d] > Fd[d]) RG_FAIL(RG_ERR_BAD_SHAPE, "upcat: skip crop outside f along dim %d", d);
+    if (og[d] + Od[d] > Gd[d] * fac[d]) RG_FAIL(RG_ERR_BAD_SHAPE, "upcat: upsample crop outside g along dim %d", d);
+  }
+  q->fd = fac[0]; q->fh = fac[1]; q->fw = fac[2]; q->ofd = of[0]; q->ofh = of[1]; q->ofw = of[2]; q->ogd = og[0]; q->ogh = og[1]; q->ogw = og[2];
+  return RG_OK;
+}
+extern "C" int rg_upcat_fwd(const rg_tensor* f, const rg_tensor* g, const rg_tensor* out, const int32_t factor[3],
+                            const int32_t off_f[3], const int32_t off_g[3], rg_stream s) {
+  CL5 F, G, O; int rc; UpcatGeom q;
+  if ((rc = rg_as_cl5(f, &F, "upcat.f")) || (rc = rg_as_cl5(g, &G, "upcat.g")) || (rc = rg_as_cl5(out, &O, "upcat.out")) ||
+      (rc = upcat_check(F, G, O, factor, off_f, off_g, &q))) return rc;
+  const long total = (long)O.N * O.D * O.H * O.W * (O.lanes / 8);
+  hipLaunchKernelGGL(upcat_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, F, G, O, q);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_upcat_bwd(const rg_tensor* gout, const rg_tensor* gf, const rg_tensor* gg, const int32_t factor[3],
+                            const int32_t off_f[3], const int32_t off_g[3], rg_stream s) {
+  CL5 F, G, O; int rc; UpcatGeom q;
+  if ((rc = rg_as_cl5(gf, &F, "upcat.gf")) || (rc = rg_as_cl5(gg, &G, "upcat.gg")) || (rc = rg_as_cl5(gout, &O, "upcat.gout")) ||
+      (rc = upcat_check(F, G, O, factor, off_f, off_g, &q))) return rc;
+  long total = (long)F.N * F.D * F.H * F.W * (F.lanes / 8);
+  hipLaunchKernelGGL(upcat_bwd_f_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, O, F, q);
+  RG_CHECK_LAUNCH();
+  total = (long)G.N * G.D * G.H * G.W * (G.lanes / 8);
+  hipLaunchKernelGGL(upcat_bwd_g_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, O, G, F.C, q);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- residual add
+__global__ void add_kernel(CL5 a, CL5 b, CL5 y) {
+  const int G8 = y.lanes / 8;
+  const long total = (long)y.N * y.D * y.H * y.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+    const bf16x8 u = *(const bf16x8*)(a.p + n * a.sn + d * a.sd + h * a.sh + w * a.sw + grp * 8);
+    const bf16x8 v = *(const bf16x8*)(b.p + n * b.sn + d * b.sd + h * b.sh + w * b.sw + grp * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (short)f2bf(bf2f((bf16_t)u[k]) + bf2f((bf16_t)v[k]));
+    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8) = o;
+  }
+}
+extern "C" int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream s) {
+  CL5 A, B, Y; int rc;
+  if ((rc = rg_as_cl5(a, &A, "add.a")) || (rc = rg_as_cl5(b, &B, "add.b")) || (rc = rg_as_cl5(y, &Y, "add.y"))) return rc;
+  if (A.N != Y.N || A.C != Y.C || A.D != Y.D || A.H != Y.H || A.W != Y.W || B.N != Y.N || B.C != Y.C || B.D != Y.D || B.H != Y.H || B.W != Y.W)
+    RG_FAIL(RG_ERR_BAD_SHAPE, "add: shape mismatch");
+  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, A, B, Y);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---------------------------------------------------------------------------- fused Adam (torch.optim.Adam, no amsgrad)
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                            float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, float grad_scale, rg_stream s) {
+  if (n == 0) return RG_OK;
+  if (!p || !g || !m || !v || n < 0 || step < 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2), grad_scale);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
