@@ -135,7 +135,9 @@ int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream
  * kind 0: mean((p-t)^2) vs constant target  (GANLoss lsgan, losses/GANLoss.py:24-25,56-58)
  * kind 1: SmoothL1(beta=1) mean vs tensor t  (LinkCycleLoss.py:22,99-106)
  * kind 2: weighted MSE of WeightedMSELoss_MTLSD._calc_loss (losses/WeightedMSELoss_MTLSD.py:11-25):
- *         out[0]=sum w*(p-t)^2, out[1]=count(w>0), out[2]=count(scaled!=0); grad is the un-normalised 2*w*(p-t). */
+ *         out[0]=sum_{w>0} w*(p-t)^2, out[1]=count(w>0), out[2]=count(scaled!=0); grad = grad_scale*2*w*(p-t) (w>0).
+ * pred/target/weight/grad: rank-1 contiguous f32 of equal length.  `out` must hold 3 + 3*512 floats (the tail is the
+ * per-workgroup partials; the three results are reduced from them in a fixed order). */
 int rg_loss_fwd_bwd(int kind, const rg_tensor* pred, const rg_tensor* target, const rg_tensor* weight, float const_target,
                     float grad_scale, const rg_tensor* grad, float* out, rg_stream s);
 

@@ -1,0 +1,98 @@
+"""ctypes binding of libraygun_hip.so (the C-ABI declared in include/raygun_hip.h).
+
+The product path has no fallback: if the library is missing or a call fails, a RuntimeError
+carrying rg_last_error_string() is raised (mirrors the RuntimeErrors the reference raises,
+networks/UNet.py:85,233,575).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libraygun_hip.so")
+
+RG_BF16, RG_F32, RG_U8, RG_I32, RG_U64, RG_F64 = range(6)
+ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3, "tanh": 4}
+
+
+class rg_tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("rank", C.c_int32),
+                ("sizes", C.c_int64 * 6), ("strides", C.c_int64 * 6)]
+
+
+class rg_pack_params(C.Structure):
+    _fields_ = [("dim0", C.c_int32), ("dim1", C.c_int32), ("K", C.c_int32 * 3), ("swap", C.c_int32),
+                ("k0", C.c_int32 * 3), ("kstep", C.c_int32 * 3), ("ntap", C.c_int32 * 3)]
+
+
+class rg_conv_params(C.Structure):
+    _fields_ = [("R", C.c_int32 * 3), ("T", C.c_int32 * 3), ("rstride", C.c_int32 * 3),
+                ("tbase", C.c_int32 * 3), ("tstep", C.c_int32 * 3), ("ostride", C.c_int32 * 3),
+                ("ooffset", C.c_int32 * 3), ("cout", C.c_int32), ("act", C.c_int32), ("slope", C.c_float)]
+
+
+class rg_mws_params(C.Structure):
+    _fields_ = [("shape", C.c_int32 * 3), ("n_offsets", C.c_int32), ("n_attractive", C.c_int32),
+                ("strides", C.c_int32 * 3), ("randomize_strides", C.c_int32)]
+
+
+_P = C.POINTER
+_T = _P(rg_tensor)
+_I3 = C.c_int32 * 3
+_SIGS = {
+    "rg_version": (C.c_int, []),
+    "rg_last_error_string": (C.c_char_p, []),
+    "rg_copy_convert": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),
+    "rg_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
+    "rg_conv3d_igemm": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p]),
+    "rg_conv3d_wgrad_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params), _P(C.c_int32)]),
+    "rg_conv3d_wgrad": (C.c_int, [_T, _T, C.c_void_p, _P(rg_conv_params), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_act_bwd_bias": (C.c_int, [_T, _T, _T, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_act_bwd_bias_workspace_bytes": (C.c_int64, [_T]),
+    "rg_maxpool3d_fwd": (C.c_int, [_T, _T, _I3, C.c_void_p]),
+    "rg_maxpool3d_bwd": (C.c_int, [_T, _T, _T, _I3, C.c_void_p]),
+    "rg_upcat_fwd": (C.c_int, [_T, _T, _T, _I3, _I3, _I3, C.c_void_p]),
+    "rg_upcat_bwd": (C.c_int, [_T, _T, _T, _I3, _I3, _I3, C.c_void_p]),
+    "rg_instnorm_workspace_bytes": (C.c_int64, [_T]),
+    "rg_instnorm_stats": (C.c_int, [_T, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_instnorm_apply": (C.c_int, [_T, C.c_void_p, _T, _T, C.c_int, C.c_float, C.c_void_p]),
+    "rg_instnorm_bwd": (C.c_int, [_T, C.c_void_p, _T, _T, _T, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_pad3d_fwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
+    "rg_pad3d_bwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
+    "rg_add": (C.c_int, [_T, _T, _T, C.c_void_p]),
+    "rg_loss_fwd_bwd": (C.c_int, [C.c_int, _T, _T, _T, C.c_float, C.c_float, _T, C.c_void_p, C.c_void_p]),
+    "rg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "rg_mws_workspace_bytes": (C.c_int64, [_P(rg_mws_params)]),
+    "rg_mws_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+}
+
+DECLARED = sorted(_SIGS)
+_lib = None
+
+
+def lib():
+    """Load the library (once).  Raises RuntimeError if it is not built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"raygun_amd: {LIB_PATH} is missing — build it with `python -m raygun_amd.build` "
+                               "(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.")
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError => symbol missing: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rg_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"raygun_amd HIP call failed ({what}, status {rc}): {msg}")
+
+
+def i3(v):
+    return _I3(*[int(a) for a in v])

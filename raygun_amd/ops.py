@@ -1,0 +1,612 @@
+"""Autograd-connected operators that call the gfx950 kernels through the C-ABI.
+
+Tensor convention between operators: a plain ``torch.Tensor`` of dtype bf16 and logical shape
+(N,C,D,H,W) whose memory is NDHWC with the channel lanes padded to a multiple of 8 and the pad
+lanes zero (include/raygun_hip.h).  Crops are zero-copy views.  Anything else handed to an
+operator (fp32 NCDHW from the user, a dense tensor autograd produced) is converted on the GPU by
+rg_copy_convert.  There is no CPU path: CPU tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT, i3, rg_conv_params, rg_pack_params, rg_tensor
+
+_DT = {torch.bfloat16: _lib.RG_BF16, torch.float32: _lib.RG_F32, torch.uint8: _lib.RG_U8,
+       torch.int32: _lib.RG_I32, torch.float64: _lib.RG_F64}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"raygun_amd.{what}: expected a CUDA/HIP tensor. The product path runs only on the "
+                           "MI355X HIP kernels; CPU execution is the oracle's job (oracle/), not a fallback.")
+
+
+def desc(t):
+    """rg_tensor descriptor of a torch tensor (rank <= 6)."""
+    d = rg_tensor()
+    d.ptr = t.data_ptr()
+    d.dtype = _DT[t.dtype]
+    d.rank = t.dim()
+    for i in range(t.dim()):
+        d.sizes[i] = t.shape[i]
+        d.strides[i] = t.stride(i)
+    return d
+
+
+def lanes_of(c):
+    return (c + 7) // 8 * 8
+
+
+def cl_empty(n, c, d, h, w, device):
+    """Uninitialised channels-last bf16 activation (every kernel writes all lanes incl. zero pad lanes)."""
+    buf = torch.empty((n, d, h, w, lanes_of(c)), dtype=torch.bfloat16, device=device)
+    return buf.permute(0, 4, 1, 2, 3)[:, :c]
+
+
+def is_cl(t):
+    if t.dtype != torch.bfloat16 or t.dim() != 5 or not t.is_cuda:
+        return False
+    n, c, d, h, w = t.shape
+    st = t.stride()
+    if c > 1 and st[1] != 1:
+        return False
+    if st[4] < lanes_of(c) or any(s % 8 for s in (st[0], st[2], st[3], st[4])):
+        return False
+    return t.data_ptr() % 16 == 0
+
+
+def to_cl(t, scale=1.0, shift=0.0):
+    """Any (N,C,D,H,W) tensor -> channels-last bf16 (no autograd; use as_cl inside Functions)."""
+    _require_cuda(t, "to_cl")
+    if t.dim() != 5:
+        raise RuntimeError(f"raygun_amd: expected a 5-D (N,C,D,H,W) tensor, got shape {tuple(t.shape)}")
+    if scale == 1.0 and shift == 0.0 and is_cl(t):
+        return t
+    if t.dtype not in (torch.bfloat16, torch.float32, torch.uint8):
+        t = t.float()
+    n, c, d, h, w = t.shape
+    out = cl_empty(n, c, d, h, w, t.device)
+    if t.numel():
+        _lib.check(_lib.lib().rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), lanes_of(c), scale, shift, _stream()),
+                   "rg_copy_convert")
+    return out
+
+
+as_cl = to_cl
+
+
+def from_cl(t, dtype=torch.float32):
+    """channels-last bf16 -> dense NCDHW `dtype` (no autograd)."""
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    if t.numel():
+        _lib.check(_lib.lib().rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), t.shape[1], 1.0, 0.0, _stream()),
+                   "rg_copy_convert")
+    return out
+
+
+class _ToCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.src_dtype = x.dtype
+        return to_cl(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return from_cl(to_cl(g), ctx.src_dtype if ctx.src_dtype.is_floating_point else torch.float32)
+
+
+class _FromCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return from_cl(to_cl(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_cl(g)
+
+
+def enter(x):
+    """Network entry: user tensor -> channels-last bf16, differentiable."""
+    _require_cuda(x, "enter")
+    if is_cl(x):
+        return x
+    return _ToCL.apply(x)
+
+
+def leave(x):
+    """Network exit: channels-last bf16 -> fp32 NCDHW contiguous, differentiable."""
+    if isinstance(x, (list, tuple)):
+        return type(x)(leave(t) for t in x)
+    if x is None or not is_cl(x):
+        return x
+    return _FromCL.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------- weights
+def _triple(v):
+    return (int(v),) * 3 if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
+    """fp32 torch-layout weight -> packed bf16 [rows16][taps][red32]; cached on the tensor per version."""
+    key = (int(swap), tuple(k0), tuple(kstep), None if ntap is None else tuple(ntap))
+    cache = getattr(w, "_rg_pack_cache", None)
+    ver = (w._version, w.data_ptr())
+    if cache is None or cache.get("ver") != ver:
+        cache = {"ver": ver}
+        try:
+            w._rg_pack_cache = cache
+        except Exception:
+            pass
+    if key in cache:
+        return cache[key]
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    p = rg_pack_params()
+    p.dim0, p.dim1 = wd.shape[0], wd.shape[1]
+    K = wd.shape[2:]
+    nt = ntap if ntap is not None else K
+    for i in range(3):
+        p.K[i], p.k0[i], p.kstep[i], p.ntap[i] = K[i], k0[i], kstep[i], nt[i]
+    p.swap = int(swap)
+    nbytes = _lib.lib().rg_pack_weights_bytes(C.byref(p))
+    if nbytes < 0:
+        raise RuntimeError("raygun_amd.pack_weights: bad packing parameters")
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
+               "rg_pack_weights")
+    cache[key] = out
+    return out
+
+
+def _conv_params(R, T, rstride, tbase, tstep, ostride, ooffset, cout, act="none", slope=0.0):
+    p = rg_conv_params()
+    for i in range(3):
+        p.R[i], p.T[i], p.rstride[i], p.tbase[i], p.tstep[i] = R[i], T[i], rstride[i], tbase[i], tstep[i]
+        p.ostride[i], p.ooffset[i] = ostride[i], ooffset[i]
+    p.cout, p.act, p.slope = cout, ACT[act], float(slope)
+    return p
+
+
+def _igemm(x, wp, bias, y, p):
+    bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
+    _lib.check(_lib.lib().rg_conv3d_igemm(C.byref(desc(x)), C.c_void_p(wp.data_ptr()), bptr, C.byref(desc(y)), C.byref(p),
+                                          _stream()), "rg_conv3d_igemm")
+
+
+def _wgrad(g, x, p, shape):
+    dw = torch.empty(shape, dtype=torch.float32, device=g.device)
+    ns = C.c_int32(0)
+    dg, dx = desc(g), desc(x)
+    nbytes = _lib.lib().rg_conv3d_wgrad_workspace_bytes(C.byref(dg), C.byref(dx), C.byref(p), C.byref(ns))
+    if nbytes < 0:
+        _lib.check(-1, "rg_conv3d_wgrad_workspace_bytes")
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+    _lib.check(_lib.lib().rg_conv3d_wgrad(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p), 0,
+                                          C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad")
+    return dw
+
+
+def _act_bwd_bias(gy, y, act, slope, want_bias):
+    """g = gy*act'(y) (new tensor unless act == none), db = per-channel sum (fp32) or None."""
+    if act == "none" and not want_bias:
+        return gy, None
+    n, c, d, h, w = gy.shape
+    g = cl_empty(n, c, d, h, w, gy.device) if act != "none" else None
+    db = torch.empty(c, dtype=torch.float32, device=gy.device) if want_bias else None
+    dgy = desc(gy)
+    nbytes = _lib.lib().rg_act_bwd_bias_workspace_bytes(C.byref(dgy)) if want_bias else 0
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
+    _lib.check(_lib.lib().rg_act_bwd_bias(C.byref(dgy), C.byref(desc(y)) if act != "none" else None,
+                                          C.byref(desc(g)) if g is not None else None,
+                                          C.c_void_p(db.data_ptr()) if want_bias else None, ACT[act], float(slope),
+                                          C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_act_bwd_bias")
+    return (g if g is not None else gy), db
+
+
+def _parity_classes(size, stride, pad, K):
+    """Per-dim decomposition of a stride-s scatter (transposed conv / strided dgrad) into stride-1 gathers.
+    For output coordinate o = s*j + q: contributing taps k = k0 + s*t, source index j + tbase - t."""
+    out = []
+    for q in range(stride):
+        rows = (size - q + stride - 1) // stride
+        k0 = (q + pad) % stride
+        nt = (K - k0 + stride - 1) // stride if K > k0 else 0
+        out.append(dict(q=q, rows=rows, k0=k0, ntap=nt, tbase=(q + pad - k0) // stride))
+    return out
+
+
+def _scatter_conv(src, w, bias, out, stride, pad, K, swap, act, slope):
+    """out[o] = act(bias + sum_{i,k: o = i*s - p + k} src[i] . W[..k])  as one igemm launch per parity class."""
+    size = out.shape[2:]
+    classes = [_parity_classes(size[i], stride[i], pad[i], K[i]) for i in range(3)]
+    if any(c["ntap"] == 0 for cl in classes for c in cl):
+        out.zero_()  # some parity class has no tap (kernel smaller than stride): bias/act of zero handled below
+        if bias is not None or act != "none":
+            raise RuntimeError("raygun_amd: transposed conv with kernel < stride and bias/activation is unsupported")
+    cout = out.shape[1]
+    for cd in classes[0]:
+        for ch in classes[1]:
+            for cw in classes[2]:
+                cs = (cd, ch, cw)
+                if any(c["rows"] <= 0 or c["ntap"] == 0 for c in cs):
+                    continue
+                wp = pack_weights(w, swap, k0=[c["k0"] for c in cs], kstep=stride, ntap=[c["ntap"] for c in cs])
+                p = _conv_params(R=[c["rows"] for c in cs], T=[c["ntap"] for c in cs], rstride=(1, 1, 1),
+                                 tbase=[c["tbase"] for c in cs], tstep=(-1, -1, -1), ostride=stride,
+                                 ooffset=[c["q"] for c in cs], cout=cout, act=act, slope=slope)
+                _igemm(src, wp, bias, out, p)
+
+
+# ---------------------------------------------------------------------------------------------- Conv3d
+class _Conv3d(torch.autograd.Function):
+    """torch.nn.Conv3d (+ fused activation), zero padding.  Reference call sites: networks/UNet.py:58-69,
+    networks/ResNet.py:283,291-298,337-338,407,416, networks/NLayerDiscriminator.py:136-176."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, act, slope):
+        _require_cuda(x, "conv3d")
+        x = as_cl(x)
+        n, cin, D, H, W = x.shape
+        cout, cin_w = weight.shape[0], weight.shape[1]
+        K = tuple(weight.shape[2:])
+        if cin_w != cin:
+            raise RuntimeError(f"Given groups=1, weight of size {list(weight.shape)}, expected input{list(x.shape)} "
+                               f"to have {cin_w} channels, but got {cin} channels instead")
+        O = [(i + 2 * p - k) // s + 1 for i, p, k, s in zip((D, H, W), padding, K, stride)]
+        if min(O) <= 0:
+            raise RuntimeError(f"Calculated padded input size per channel: {tuple(i + 2 * p for i, p in zip((D, H, W), padding))}. "
+                               f"Kernel size: {K}. Kernel size can't be greater than actual input size")
+        y = cl_empty(n, cout, *O, x.device)
+        wp = pack_weights(weight, swap=0)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
+                         ooffset=(0, 0, 0), cout=cout, act=act, slope=slope)
+        _igemm(x, wp, b, y, p)
+        ctx.save_for_backward(x, weight, y if act != "none" else None)
+        ctx.cfg = (stride, padding, act, slope, bias is not None, K, O)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, padding, act, slope, has_bias, K, O = ctx.cfg
+        gy = as_cl(gy)
+        g, db = _act_bwd_bias(gy, y, act, slope, has_bias and ctx.needs_input_grad[2])
+        gx = dw = None
+        n, cin, D, H, W = x.shape
+        if ctx.needs_input_grad[0]:
+            gx = cl_empty(n, cin, D, H, W, x.device)
+            if stride == (1, 1, 1):
+                wp = pack_weights(weight, swap=1)
+                p = _conv_params(R=(D, H, W), T=K, rstride=(1, 1, 1), tbase=padding, tstep=(-1, -1, -1),
+                                 ostride=(1, 1, 1), ooffset=(0, 0, 0), cout=cin)
+                _igemm(g, wp, None, gx, p)
+            else:
+                _scatter_conv(g, weight, None, gx, stride, padding, K, swap=1, act="none", slope=0.0)
+        if ctx.needs_input_grad[1]:
+            p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
+                             ooffset=(0, 0, 0), cout=weight.shape[0])
+            dw = _wgrad(g, x, p, weight.shape).to(weight.dtype)
+        if db is not None:
+            db = db.to(weight.dtype)
+        return gx, dw, db, None, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
+    return _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), act, float(slope))
+
+
+class _ConvTranspose3d(torch.autograd.Function):
+    """torch.nn.ConvTranspose3d (+ fused activation).  Reference: networks/ResNet.py:325-333, networks/UNet.py:263-269."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding, act, slope):
+        _require_cuda(x, "conv_transpose3d")
+        x = as_cl(x)
+        n, cin, D, H, W = x.shape
+        if weight.shape[0] != cin:
+            raise RuntimeError(f"ConvTranspose3d: expected input with {weight.shape[0]} channels, got {cin}")
+        cout = weight.shape[1]
+        K = tuple(weight.shape[2:])
+        O = [(i - 1) * s - 2 * p + k + op for i, s, p, k, op in zip((D, H, W), stride, padding, K, output_padding)]
+        y = cl_empty(n, cout, *O, x.device)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        _scatter_conv(x, weight, b, y, stride, padding, K, swap=1, act=act, slope=slope)
+        ctx.save_for_backward(x, weight, y if act != "none" else None)
+        ctx.cfg = (stride, padding, act, slope, bias is not None, K, O)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        stride, padding, act, slope, has_bias, K, O = ctx.cfg
+        gy = as_cl(gy)
+        g, db = _act_bwd_bias(gy, y, act, slope, has_bias and ctx.needs_input_grad[2])
+        gx = dw = None
+        n, cin, D, H, W = x.shape
+        p = _conv_params(R=(D, H, W), T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1),
+                         ostride=(1, 1, 1), ooffset=(0, 0, 0), cout=cin)
+        if ctx.needs_input_grad[0]:
+            gx = cl_empty(n, cin, D, H, W, x.device)
+            _igemm(g, pack_weights(weight, swap=0), None, gx, p)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(x, g, p, weight.shape).to(weight.dtype)
+        if db is not None:
+            db = db.to(weight.dtype)
+        return gx, dw, db, None, None, None, None, None
+
+
+def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0, act="none", slope=0.0):
+    return _ConvTranspose3d.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(output_padding), act,
+                                  float(slope))
+
+
+# ---------------------------------------------------------------------------------------------- activation
+class _Act(torch.autograd.Function):
+    """Stand-alone activation (when it cannot be fused into a conv / norm epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = as_cl(x)
+        n, c, d, h, w = x.shape
+        y = cl_empty(n, c, d, h, w, x.device)
+        # identity "norm" (mean 0, rstd 1) + activation == plain activation: reuse the fused apply kernel
+        mr = torch.tensor([0.0, 1.0], dtype=torch.float32, device=x.device).repeat(n * c)
+        _lib.check(_lib.lib().rg_instnorm_apply(C.byref(desc(x)), C.c_void_p(mr.data_ptr()), None, C.byref(desc(y)),
+                                                ACT[act], float(slope), _stream()), "rg_instnorm_apply")
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        g, _ = _act_bwd_bias(as_cl(gy), y, ctx.cfg[0], ctx.cfg[1], False)
+        return g, None, None
+
+
+def activation(x, act, slope=0.0):
+    _require_cuda(x, "activation")
+    if act == "none":
+        return x
+    return _Act.apply(x, act, float(slope))
+
+
+# ---------------------------------------------------------------------------------------------- max pool
+class _MaxPool3d(torch.autograd.Function):
+    """torch.nn.MaxPool3d(k, stride=k) floor mode (MaxDownsample, networks/UNet.py:209-228)."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        _require_cuda(x, "maxpool3d")
+        x = as_cl(x)
+        n, c, D, H, W = x.shape
+        O = [D // factor[0], H // factor[1], W // factor[2]]
+        if min(O) <= 0:
+            raise RuntimeError(f"max_pool3d(): output size too small for input {tuple(x.shape)} and kernel {factor}")
+        y = cl_empty(n, c, *O, x.device)
+        _lib.check(_lib.lib().rg_maxpool3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(factor), _stream()), "rg_maxpool3d_fwd")
+        ctx.save_for_backward(x)
+        ctx.factor = factor
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = as_cl(gy)
+        n, c, D, H, W = x.shape
+        gx = cl_empty(n, c, D, H, W, x.device)
+        _lib.check(_lib.lib().rg_maxpool3d_bwd(C.byref(desc(x)), C.byref(desc(gy)), C.byref(desc(gx)), i3(ctx.factor), _stream()),
+                   "rg_maxpool3d_bwd")
+        return gx, None
+
+
+def maxpool3d(x, factor):
+    return _MaxPool3d.apply(x, _triple(factor))
+
+
+# ---------------------------------------------------------------------------------------------- upsample+crop+concat
+class _UpCat(torch.autograd.Function):
+    """cat([centre_crop(f), centre_crop(nearest_upsample(g))], 1) — Upsample.forward, networks/UNet.py:338-351."""
+
+    @staticmethod
+    def forward(ctx, f, g, factor, out_spatial):
+        _require_cuda(f, "upcat")
+        f, g = as_cl(f), as_cl(g)
+        n, cf = f.shape[:2]
+        cg = g.shape[1]
+        up = [a * b for a, b in zip(g.shape[2:], factor)]
+        off_g = [(a - b) // 2 for a, b in zip(up, out_spatial)]
+        off_f = [(a - b) // 2 for a, b in zip(f.shape[2:], out_spatial)]
+        out = cl_empty(n, cf + cg, *out_spatial, f.device)
+        _lib.check(_lib.lib().rg_upcat_fwd(C.byref(desc(f)), C.byref(desc(g)), C.byref(desc(out)), i3(factor), i3(off_f),
+                                           i3(off_g), _stream()), "rg_upcat_fwd")
+        ctx.cfg = (factor, off_f, off_g, tuple(f.shape), tuple(g.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        factor, off_f, off_g, fs, gs = ctx.cfg
+        go = as_cl(go)
+        gf = cl_empty(*fs, go.device)
+        gg = cl_empty(*gs, go.device)
+        _lib.check(_lib.lib().rg_upcat_bwd(C.byref(desc(go)), C.byref(desc(gf)), C.byref(desc(gg)), i3(factor), i3(off_f),
+                                           i3(off_g), _stream()), "rg_upcat_bwd")
+        return gf, gg, None, None
+
+
+def upcat(f, g, factor, out_spatial):
+    return _UpCat.apply(f, g, _triple(factor), tuple(int(v) for v in out_spatial))
+
+
+# ---------------------------------------------------------------------------------------------- instance norm
+class _InstanceNorm(torch.autograd.Function):
+    """InstanceNorm3d(affine=False, track_running_stats=False) [+act] [+residual]  (networks/ResNet.py:284-285,
+    408-409,417,436-443; NLayerDiscriminator.py:154-156)."""
+
+    @staticmethod
+    def forward(ctx, x, res, eps, act, slope):
+        _require_cuda(x, "instance_norm")
+        x = as_cl(x)
+        if res is not None:
+            if act != "none":
+                raise RuntimeError("raygun_amd.instance_norm: residual add is fused only without activation")
+            res = as_cl(res)
+        n, c, d, h, w = x.shape
+        L = _lib.lib()
+        dx = desc(x)
+        nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        mr = torch.empty(n * c * 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.rg_instnorm_stats(C.byref(dx), C.c_void_p(mr.data_ptr()), float(eps), C.c_void_p(ws.data_ptr()), nbytes,
+                                       _stream()), "rg_instnorm_stats")
+        y = cl_empty(n, c, d, h, w, x.device)
+        _lib.check(L.rg_instnorm_apply(C.byref(dx), C.c_void_p(mr.data_ptr()), C.byref(desc(res)) if res is not None else None,
+                                       C.byref(desc(y)), ACT[act], float(slope), _stream()), "rg_instnorm_apply")
+        ctx.save_for_backward(x, mr, y if act != "none" else None)
+        ctx.cfg = (act, slope, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mr, y = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        gy = as_cl(gy)
+        n, c, d, h, w = x.shape
+        gx = None
+        if ctx.needs_input_grad[0]:
+            L = _lib.lib()
+            dx = desc(x)
+            nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            gx = cl_empty(n, c, d, h, w, x.device)
+            _lib.check(L.rg_instnorm_bwd(C.byref(dx), C.c_void_p(mr.data_ptr()), C.byref(desc(y)) if y is not None else None,
+                                         C.byref(desc(gy)), C.byref(desc(gx)), ACT[act], float(slope),
+                                         C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_instnorm_bwd")
+        return gx, (gy if has_res and ctx.needs_input_grad[1] else None), None, None, None
+
+
+def instance_norm(x, eps=1e-5, act="none", slope=0.0, residual=None):
+    return _InstanceNorm.apply(x, residual, float(eps), act, float(slope))
+
+
+# ---------------------------------------------------------------------------------------------- padding / add
+class _Pad3d(torch.autograd.Function):
+    """ReflectionPad3d / zero pad (networks/ResNet.py:270,337,392)."""
+
+    @staticmethod
+    def forward(ctx, x, pad, mode):
+        _require_cuda(x, "pad3d")
+        x = as_cl(x)
+        n, c, d, h, w = x.shape
+        if mode == 1 and any(p >= s for p, s in zip(pad, (d, h, w))):
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                               f"but got: padding {pad} at input {tuple(x.shape)}")
+        y = cl_empty(n, c, d + 2 * pad[0], h + 2 * pad[1], w + 2 * pad[2], x.device)
+        _lib.check(_lib.lib().rg_pad3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(pad), mode, _stream()), "rg_pad3d_fwd")
+        ctx.cfg = (pad, mode, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        pad, mode, xs = ctx.cfg
+        gy = as_cl(gy)
+        gx = cl_empty(*xs, gy.device)
+        _lib.check(_lib.lib().rg_pad3d_bwd(C.byref(desc(gy)), C.byref(desc(gx)), i3(pad), mode, _stream()), "rg_pad3d_bwd")
+        return gx, None, None
+
+
+def pad3d(x, pad, mode="reflect"):
+    return _Pad3d.apply(x, _triple(pad), {"zeros": 0, "reflect": 1}[mode])
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a, "add")
+        a, b = as_cl(a), as_cl(b)
+        y = cl_empty(*a.shape, a.device)
+        _lib.check(_lib.lib().rg_add(C.byref(desc(a)), C.byref(desc(b)), C.byref(desc(y)), _stream()), "rg_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def center_crop(x, shape):
+    """Zero-copy centre crop (networks/UNet.py:97-106,327-336)."""
+    off = [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)]
+    return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
+
+
+# ---------------------------------------------------------------------------------------------- losses
+_LOSS_OUT = 3 + 3 * 512
+
+
+class _Loss(torch.autograd.Function):
+    """Fused loss value + gradient (losses/GANLoss.py:56-58, LinkCycleLoss.py:99-106, WeightedMSELoss_MTLSD.py:11-25)."""
+
+    @staticmethod
+    def forward(ctx, kind, pred, target, weight, const_target):
+        _require_cuda(pred, "loss")
+        p = pred.detach().float().contiguous().view(-1)
+        t = target.detach().float().contiguous().view(-1) if target is not None else None
+        w = weight.detach().float().contiguous().view(-1) if weight is not None else None
+        if t is not None and t.numel() != p.numel():
+            raise RuntimeError(f"The size of tensor a ({tuple(pred.shape)}) must match the size of tensor b ({tuple(target.shape)})")
+        out = torch.empty(_LOSS_OUT, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        _lib.check(_lib.lib().rg_loss_fwd_bwd(kind, C.byref(desc(p)), C.byref(desc(t)) if t is not None else None,
+                                              C.byref(desc(w)) if w is not None else None, float(const_target), 1.0,
+                                              C.byref(desc(grad)), C.c_void_p(out.data_ptr()), _stream()), "rg_loss_fwd_bwd")
+        n = p.numel()
+        if kind == 2:
+            # WeightedMSELoss_MTLSD.py:15-23 without the host sync: mean over w>0 if any scaled != 0 else mean(scaled) (== 0)
+            cnt = torch.clamp(out[1], min=1.0)
+            loss = torch.where(out[2] > 0, out[0] / cnt, out[0] * 0.0)
+            gnorm = torch.where(out[2] > 0, 1.0 / cnt, out[0] * 0.0)
+        else:
+            loss = out[0] / n
+            gnorm = torch.full((), 1.0 / n, dtype=torch.float32, device=p.device)
+        ctx.save_for_backward(grad, gnorm)
+        ctx.shape, ctx.dtype = pred.shape, pred.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        grad, gnorm = ctx.saved_tensors
+        g = (grad * (gnorm * gl)).view(ctx.shape).to(ctx.dtype)
+        return None, g, None, None, None
+
+
+def mse_const(pred, target_value):
+    return _Loss.apply(0, pred, None, None, float(target_value))
+
+
+def smooth_l1(pred, target):
+    return _Loss.apply(1, pred, target, None, 0.0)
+
+
+def weighted_mse(pred, target, weight):
+    return _Loss.apply(2, pred, target, weight, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- Adam
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place fused Adam on flat fp32 tensors (torch.optim.Adam semantics; optimizers/utils.py:4-9)."""
+    _lib.check(_lib.lib().rg_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                       C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                       grad_scale, _stream()), "rg_adam_step")

@@ -1,0 +1,232 @@
+"""GPU parity of every operator (through the C-ABI) against plain torch fp32 on the CPU.
+
+Inputs/weights are rounded to bf16 first so that the only differences are accumulation order and
+the bf16 rounding of the stored result: tolerance 1.5e-2 of the tensor's max-abs (bf16 has 8
+significant bits: one output rounding is <= 2^-9 relative; gradients pass through 2-3 roundings).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from raygun_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1.5e-2
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return bf(torch.from_numpy(synth.uniform(shape, seed, lo, hi)))
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def run_pair(hip_fn, ref_fn, inputs, params, gseed=7):
+    """inputs/params: lists of CPU fp32 tensors. Returns errors for output, input grads, param grads."""
+    dev = torch.device("cuda")
+    xi = [t.clone().to(dev).requires_grad_(True) for t in inputs]
+    pi = [t.clone().to(dev).requires_grad_(True) for t in params]
+    y = hip_fn(*xi, *pi)
+    xr = [t.clone().requires_grad_(True) for t in inputs]
+    pr = [t.clone().requires_grad_(True) for t in params]
+    yr = ref_fn(*xr, *pr)
+    g = rnd(tuple(yr.shape), gseed)
+    y.backward(g.to(dev).to(y.dtype))
+    yr.backward(g)
+    errs = {"y": relerr(y, yr)}
+    for i, (a, b) in enumerate(zip(xi, xr)):
+        errs[f"gx{i}"] = relerr(a.grad, b.grad)
+    for i, (a, b) in enumerate(zip(pi, pr)):
+        errs[f"gp{i}"] = relerr(a.grad, b.grad)
+    return errs
+
+
+def check(errs, tol=TOL):
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, f"errors above {tol}: {bad} (all: {errs})"
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, spatial, act
+    (3, 5, 3, 1, 0, (10, 9, 11), "relu"),
+    (1, 12, 3, 1, 0, (12, 12, 12), "relu"),
+    (12, 12, 3, 1, 0, (9, 10, 11), "none"),
+    (72, 40, 3, 1, 0, (7, 8, 9), "relu"),
+    (40, 144, 3, 1, 1, (6, 6, 6), "leaky"),
+    (16, 8, 1, 1, 0, (5, 6, 7), "sigmoid"),
+    (8, 16, 3, 2, 1, (9, 10, 12), "none"),
+    (1, 8, 4, 2, 1, (12, 12, 12), "leaky"),
+    (8, 8, 4, 1, 1, (7, 7, 7), "none"),
+    (4, 6, 7, 1, 0, (9, 9, 10), "none"),
+    (200, 24, 3, 1, 0, (5, 5, 6), "relu"),
+    (6, 4, (3, 1, 2), (2, 1, 1), (1, 0, 0), (8, 6, 7), "none"),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,sp,act", CONV_CASES)
+def test_conv3d(cin, cout, k, s, p, sp, act):
+    from raygun_amd import ops
+    kk = (k,) * 3 if isinstance(k, int) else k
+    x = rnd((2, cin) + sp, 1)
+    w = rnd((cout, cin) + kk, 2) * (1.0 / np.sqrt(cin * np.prod(kk)))
+    w = bf(w)
+    b = rnd((cout,), 3)
+    afn = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.2), "sigmoid": torch.sigmoid}[act]
+    errs = run_pair(lambda x_, w_, b_: ops.conv3d(x_, w_, b_, s, p, act, 0.2),
+                    lambda x_, w_, b_: afn(F.conv3d(x_, w_, b_, s, p)), [x], [w, b])
+    check(errs)
+
+
+CONVT_CASES = [
+    (8, 6, 3, 2, 1, 1, (5, 6, 7), "none"),
+    (16, 8, 3, 2, 1, 1, (4, 4, 5), "relu"),
+    (4, 4, 2, 2, 0, 0, (5, 5, 5), "none"),
+    (6, 10, 3, 1, 1, 0, (5, 6, 4), "none"),
+    (4, 3, 3, 2, 0, 0, (4, 5, 6), "none"),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,op,sp,act", CONVT_CASES)
+def test_conv_transpose3d(cin, cout, k, s, p, op, sp, act):
+    from raygun_amd import ops
+    x = rnd((2, cin) + sp, 11)
+    w = bf(rnd((cin, cout, k, k, k), 12) * (1.0 / np.sqrt(cin * k ** 3)))
+    b = rnd((cout,), 13)
+    afn = {"none": lambda t: t, "relu": F.relu}[act]
+    errs = run_pair(lambda x_, w_, b_: ops.conv_transpose3d(x_, w_, b_, s, p, op, act),
+                    lambda x_, w_, b_: afn(F.conv_transpose3d(x_, w_, b_, s, p, op)), [x], [w, b])
+    check(errs)
+
+
+def test_conv_no_bias_and_frozen_weight():
+    from raygun_amd import ops
+    x = rnd((1, 8, 6, 6, 6), 21)
+    w = bf(rnd((8, 8, 3, 3, 3), 22) * 0.1)
+    dev = torch.device("cuda")
+    xi = x.to(dev).requires_grad_(True)
+    wi = w.to(dev)  # no grad: discriminator frozen during the generator phase (LinkCycleLoss.py:117-119)
+    y = ops.conv3d(xi, wi, None, 1, 1)
+    y.float().sum().backward()
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, None, 1, 1)
+    yr.sum().backward()
+    assert relerr(y, yr) < TOL and relerr(xi.grad, xr.grad) < TOL
+
+
+@pytest.mark.parametrize("shape,factor", [((1, 3, 9, 7, 8), (2, 2, 2)), ((2, 12, 8, 8, 8), (2, 2, 2)),
+                                          ((1, 20, 6, 9, 6), (1, 3, 2))])
+def test_maxpool(shape, factor):
+    from raygun_amd import ops
+    x = rnd(shape, 31)
+    errs = run_pair(lambda t: ops.maxpool3d(t, factor), lambda t: F.max_pool3d(t, factor, factor), [x], [])
+    check(errs, 1e-6)
+
+
+@pytest.mark.parametrize("cf,cg", [(3, 4), (12, 72), (8, 16), (72, 432)])
+def test_upcat(cf, cg):
+    from raygun_amd import ops
+    f = rnd((1, cf, 20, 20, 20), 41)
+    g = rnd((1, cg, 7, 7, 7), 42)
+
+    def ref(f_, g_):
+        up = F.interpolate(g_, scale_factor=(2, 2, 2), mode="nearest")[..., 1:13, 1:13, 1:13]
+        return torch.cat([f_[..., 4:16, 4:16, 4:16], up], 1)
+
+    errs = run_pair(lambda f_, g_: ops.upcat(f_, g_, (2, 2, 2), (12, 12, 12)), ref, [f, g], [])
+    check(errs, 4e-3)  # gg sums 8 bf16 values then rounds once
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "leaky"])
+@pytest.mark.parametrize("c", [5, 64])
+def test_instance_norm(act, c):
+    from raygun_amd import ops
+    x = bf(rnd((2, c, 6, 7, 8), 51) * 3 + 1)
+    afn = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    errs = run_pair(lambda t: ops.instance_norm(t, 1e-5, act, 0.2), lambda t: afn(F.instance_norm(t, eps=1e-5)), [x], [])
+    check(errs)
+
+
+def test_instance_norm_residual():
+    from raygun_amd import ops
+    x = bf(rnd((1, 16, 6, 6, 6), 52) * 2)
+    r = rnd((1, 16, 6, 6, 6), 53)
+    errs = run_pair(lambda t, r_: ops.instance_norm(t, 1e-5, "none", 0.0, r_), lambda t, r_: F.instance_norm(t) + r_, [x, r], [])
+    check(errs)
+
+
+@pytest.mark.parametrize("mode", ["reflect", "zeros"])
+@pytest.mark.parametrize("pad", [1, 3])
+def test_pad3d(mode, pad):
+    from raygun_amd import ops
+    x = rnd((2, 5, 6, 7, 8), 61)
+    ref = (lambda t: F.pad(t, (pad,) * 6, mode="reflect")) if mode == "reflect" else (lambda t: F.pad(t, (pad,) * 6))
+    errs = run_pair(lambda t: ops.pad3d(t, pad, mode), ref, [x], [])
+    check(errs, 4e-3)
+
+
+def test_add_and_activation():
+    from raygun_amd import ops
+    a, b = rnd((1, 12, 5, 5, 5), 71), rnd((1, 12, 5, 5, 5), 72)
+    check(run_pair(ops.add, lambda p, q: p + q, [a, b], []), 4e-3)
+    check(run_pair(lambda t: ops.activation(t, "leaky", 0.2), lambda t: F.leaky_relu(t, 0.2), [a], []), 4e-3)
+    check(run_pair(lambda t: ops.activation(t, "sigmoid"), torch.sigmoid, [a], []), 8e-3)
+
+
+def test_losses():
+    from raygun_amd import ops
+    p = torch.from_numpy(synth.uniform((1, 3, 9, 9, 9), 81))
+    t = torch.from_numpy(synth.uniform((1, 3, 9, 9, 9), 82))
+    w = (torch.from_numpy(synth.uniform((1, 3, 9, 9, 9), 83)) > 0.2).float() * 1.5
+
+    def wmse(p_, t_, w_):
+        sc = w_ * (p_ - t_) ** 2
+        return sc[w_ > 0].mean() if len(torch.nonzero(sc)) else sc.mean()
+
+    dev = torch.device("cuda")
+    for hip, ref in [(lambda q: ops.mse_const(q, 1.0), lambda q: F.mse_loss(q, torch.ones_like(q))),
+                     (lambda q: ops.smooth_l1(q * 3, t.to(q.device) * 3), lambda q: F.smooth_l1_loss(q * 3, t * 3)),
+                     (lambda q: ops.weighted_mse(q, t.to(q.device), w.to(q.device)), lambda q: wmse(q, t, w)),
+                     (lambda q: ops.weighted_mse(q, t.to(q.device), 0 * w.to(q.device)), lambda q: wmse(q, t, 0 * w))]:
+        a = p.clone().to(dev).requires_grad_(True)
+        b = p.clone().requires_grad_(True)
+        la, lb = hip(a), ref(b)
+        (la * 2).backward(); (lb * 2).backward()
+        assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 1e-6 + 1e-5 * float(b.grad.abs().max())
+
+
+def test_adam_matches_torch():
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    p0 = torch.from_numpy(synth.normal((1000,), 91))
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.5, 0.999), weight_decay=0.01)
+    p = p0.clone().to(dev); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 4):
+        g = torch.from_numpy(synth.normal((1000,), 92 + step))
+        ref.grad = g.clone(); opt.step()
+        ops.adam_step_(p, g.to(dev), m, v, 1e-2, 0.5, 0.999, 1e-8, 0.01, step)
+    assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+
+
+def test_cpu_tensor_raises():
+    from raygun_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv3d(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 3, 3, 3))
+
+
+def test_shape_errors_raise():
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv3d(torch.zeros(1, 2, 4, 4, 4, device=dev), torch.zeros(1, 3, 3, 3, 3, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.conv3d(torch.zeros(1, 1, 2, 2, 2, device=dev), torch.zeros(1, 1, 3, 3, 3, device=dev))
