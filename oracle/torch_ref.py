@@ -672,3 +672,38 @@ def mtlsd_step(model, loss_fn, opt, raw, gt_lsds, w_lsds, gt_affs, w_affs):
     loss.backward()
     opt.step()
     return loss, affs, lsds
+
+
+# ----------------------------------------------------------------------------- bf16 storage emulation
+class _RoundBF16(torch.autograd.Function):
+    """Round-trip through bfloat16 in forward AND backward (what storing a tensor in bf16 does)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def round_bf16(x):
+    return _RoundBF16.apply(x)
+
+
+def emulate_bf16(module):
+    """Turn a restated network into a model of the HIP path's PRECISION POLICY (bf16 storage of every activation
+    and weight operand, fp32 arithmetic): weights are rounded to bf16 in place and every leaf layer's output is
+    rounded through bf16 in both directions.  ReLU/max-pool decisions then agree with the GPU's except where fp32
+    accumulation order matters, which is what makes gradient parity testable at all: against a pure-fp32 run a
+    bf16 network's gradient differs by ~sqrt(P[sign flip]) in relative L2 however correct the kernels are.
+    Returns the hook handles (call .remove() on each to undo)."""
+    handles = []
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.dim() > 1:
+                p.copy_(p.to(torch.bfloat16).float())
+    for m in module.modules():
+        if len(list(m.children())) == 0 and not isinstance(m, nn.Identity):
+            handles.append(m.register_forward_hook(lambda mod, inp, out: round_bf16(out)))
+    return handles

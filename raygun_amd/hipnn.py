@@ -1,0 +1,254 @@
+"""Drop-in layer classes: torch.nn subclasses (same constructors, parameters, state_dict keys,
+class names — so init_weights / set_norm_mode / load_state_dict of the reference keep working)
+whose forward runs the gfx950 kernels.
+
+Scoping: inside a raygun_amd network, activations travel as channels-last bf16 tensors; the
+OUTERMOST raygun_amd module of a call converts its result to the fp32 NCDHW tensor the reference
+would have returned (``scope()`` tracks the nesting).
+"""
+import contextlib
+import functools
+import threading
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def scope():
+    """Yields True for the outermost raygun_amd module of the current call stack."""
+    depth = getattr(_tls, "depth", 0)
+    _tls.depth = depth + 1
+    try:
+        yield depth == 0
+    finally:
+        _tls.depth = depth
+
+
+def scoped(forward):
+    """Decorator for Module.forward: run inside a scope; leave channels-last at the outermost level."""
+    @functools.wraps(forward)
+    def wrapper(self, *args, **kwargs):
+        with scope() as outer:
+            y = forward(self, *args, **kwargs)
+        return ops.leave(y) if outer else y
+    return wrapper
+
+
+def _symmetric(pad6_or_int, what):
+    if isinstance(pad6_or_int, int):
+        return (pad6_or_int,) * 3
+    p = tuple(pad6_or_int)
+    if len(p) == 3:
+        return p
+    if len(p) == 6 and p[0] == p[1] and p[2] == p[3] and p[4] == p[5]:
+        return (p[4], p[2], p[0])  # F.pad order is (W_l, W_r, H_l, H_r, D_l, D_r)
+    raise RuntimeError(f"raygun_amd.{what}: only symmetric padding is supported, got {p}")
+
+
+_ACT_OF = {}
+
+
+def act_of(m):
+    """(kind, slope) if module `m` is an activation the kernels can fuse, else None."""
+    for cls, fn in _ACT_OF.items():
+        if isinstance(m, cls):
+            return fn(m)
+    return None
+
+
+class ReLU(nn.ReLU):
+    @scoped
+    def forward(self, x):
+        return ops.activation(x, "relu")
+
+
+class LeakyReLU(nn.LeakyReLU):
+    @scoped
+    def forward(self, x):
+        return ops.activation(x, "leaky", self.negative_slope)
+
+
+class Sigmoid(nn.Sigmoid):
+    @scoped
+    def forward(self, x):
+        return ops.activation(x, "sigmoid")
+
+
+class Tanh(nn.Tanh):
+    @scoped
+    def forward(self, x):
+        return ops.activation(x, "tanh")
+
+
+class Identity(nn.Identity):
+    pass
+
+
+_ACT_OF.update({nn.ReLU: lambda m: ("relu", 0.0), nn.LeakyReLU: lambda m: ("leaky", m.negative_slope),
+                nn.Sigmoid: lambda m: ("sigmoid", 0.0), nn.Tanh: lambda m: ("tanh", 0.0)})
+
+
+class Conv3d(nn.Conv3d):
+    """torch.nn.Conv3d on the implicit-GEMM kernel.  padding int/tuple/'valid'/'same'; padding_mode zeros|reflect."""
+
+    def _pads(self):
+        if isinstance(self.padding, str):
+            if self.padding == "valid":
+                return (0, 0, 0)
+            tot = [d * (k - 1) for d, k in zip(self.dilation, self.kernel_size)]
+            if any(t % 2 for t in tot):
+                raise RuntimeError("raygun_amd.Conv3d: padding='same' needs odd kernels")
+            return tuple(t // 2 for t in tot)
+        return tuple(self.padding)
+
+    def _check(self):
+        if self.groups != 1 or any(d != 1 for d in self.dilation):
+            raise RuntimeError("raygun_amd.Conv3d: groups/dilation != 1 are not built (use torch.nn.Conv3d)")
+        if self.padding_mode not in ("zeros", "reflect"):
+            raise RuntimeError(f"raygun_amd.Conv3d: padding_mode {self.padding_mode!r} is not built")
+
+    def run(self, x, act="none", slope=0.0):
+        self._check()
+        pads = self._pads()
+        if self.padding_mode == "reflect" and any(pads):
+            x = ops.pad3d(x, pads, "reflect")
+            pads = (0, 0, 0)
+        return ops.conv3d(x, self.weight, self.bias, self.stride, pads, act, slope)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class ConvTranspose3d(nn.ConvTranspose3d):
+    def run(self, x, act="none", slope=0.0):
+        if self.groups != 1 or any(d != 1 for d in self.dilation):
+            raise RuntimeError("raygun_amd.ConvTranspose3d: groups/dilation != 1 are not built")
+        return ops.conv_transpose3d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class InstanceNorm3d(nn.InstanceNorm3d):
+    """affine=False, track_running_stats=False runs on the HIP kernels (the only form get_network builds for the
+    hot path: systems/BaseSystem.py:193-199, networks/ResNet.py:231-262 default).  Other forms use torch's op."""
+
+    def hip_ok(self):
+        return not self.affine and not self.track_running_stats
+
+    def run(self, x, act="none", slope=0.0, residual=None):
+        if not self.hip_ok():
+            y = passthrough(super().forward, x)
+            if residual is not None:
+                y = ops.add(y, residual)
+            return ops.activation(y, act, slope)
+        return ops.instance_norm(x, self.eps, act, slope, residual)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class ReflectionPad3d(nn.ReflectionPad3d):
+    @scoped
+    def forward(self, x):
+        return ops.pad3d(x, _symmetric(self.padding, "ReflectionPad3d"), "reflect")
+
+
+class MaxPool3d(nn.MaxPool3d):
+    @scoped
+    def forward(self, x):
+        ks = (self.kernel_size,) * 3 if isinstance(self.kernel_size, int) else tuple(self.kernel_size)
+        st = (self.stride,) * 3 if isinstance(self.stride, int) else tuple(self.stride)
+        if ks != st or self.padding not in (0, (0, 0, 0)) or self.ceil_mode:
+            raise RuntimeError("raygun_amd.MaxPool3d: only kernel == stride, no padding, floor mode is built")
+        return ops.maxpool3d(x, ks)
+
+
+def passthrough(fn, x, *args, **kwargs):
+    """Run a torch op that has no HIP kernel here (dropout, noise blocks, affine norms) on a dense fp32 view."""
+    dense = ops.leave(x) if ops.is_cl(x) else x
+    return fn(dense, *args, **kwargs)
+
+
+_HIP_LAYER = {"Conv3d": Conv3d, "ConvTranspose3d": ConvTranspose3d, "InstanceNorm3d": InstanceNorm3d,
+              "ReflectionPad3d": ReflectionPad3d, "MaxPool3d": MaxPool3d, "ReLU": ReLU, "LeakyReLU": LeakyReLU,
+              "Sigmoid": Sigmoid, "Tanh": Tanh}
+
+
+def hip_layer(factory):
+    """Map a torch.nn layer class / functools.partial / name to its raygun_amd twin (unknown ones unchanged)."""
+    if factory is None:
+        return None
+    if isinstance(factory, str):
+        return _HIP_LAYER.get(factory, getattr(nn, factory))
+    if isinstance(factory, functools.partial):
+        return functools.partial(hip_layer(factory.func), *factory.args, **factory.keywords)
+    if isinstance(factory, type) and factory.__module__.startswith("torch.nn") and factory.__name__ in _HIP_LAYER:
+        return _HIP_LAYER[factory.__name__]
+    return factory
+
+
+def is_instance_norm_factory(factory, nd=3):
+    """`use_bias = norm_layer == InstanceNorm3d` of the reference (networks/ResNet.py:259-262), for either class."""
+    base = factory.func if isinstance(factory, functools.partial) else factory
+    return base in (getattr(nn, f"InstanceNorm{nd}d"), InstanceNorm3d)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential (same indices / state_dict keys / len) whose forward fuses
+    [pad] conv [InstanceNorm] [activation]  into conv-epilogue / norm-apply kernels."""
+
+    def run(self, x, residual=None):
+        mods = list(self)
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            last = lambda j: j >= n  # noqa: E731
+            if isinstance(m, (Conv3d, ConvTranspose3d)):
+                nxt = mods[i + 1] if i + 1 < n else None
+                a = act_of(nxt) if nxt is not None else None
+                if a is not None:
+                    x = m.run(x, a[0], a[1]); i += 2
+                elif isinstance(nxt, InstanceNorm3d):
+                    x = m.run(x)
+                    a2 = act_of(mods[i + 2]) if i + 2 < n else None
+                    if a2 is not None:
+                        x = nxt.run(x, a2[0], a2[1]); i += 3
+                    else:
+                        fuse_res = residual if (i + 2 >= n) else None
+                        x = nxt.run(x, residual=fuse_res); i += 2
+                        if fuse_res is not None:
+                            residual = None
+                else:
+                    x = m.run(x); i += 1
+            elif isinstance(m, InstanceNorm3d):
+                a = act_of(mods[i + 1]) if i + 1 < n else None
+                if a is not None:
+                    x = m.run(x, a[0], a[1]); i += 2
+                else:
+                    x = m.run(x); i += 1
+            elif act_of(m) is not None and not isinstance(m, (ReLU, LeakyReLU, Sigmoid, Tanh)):
+                a = act_of(m)  # a plain torch.nn activation instance handed in by the user
+                x = ops.activation(x, a[0], a[1]); i += 1
+            elif isinstance(m, (ReflectionPad3d, MaxPool3d, ReLU, LeakyReLU, Sigmoid, Tanh, FusedSequential)) or \
+                    getattr(m, "_raygun_amd", False):
+                x = m(x); i += 1
+            elif isinstance(m, nn.Identity):
+                i += 1
+            else:
+                x = passthrough(m, x); i += 1
+        if residual is not None:
+            x = ops.add(x, residual)
+        return x
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)

@@ -1,0 +1,280 @@
+"""3-D U-Net on the gfx950 kernels — drop-in for raygun.torch.networks.UNet
+(reference: src/raygun/torch/networks/UNet.py; constructor signatures, attributes, state_dict keys
+and error behaviour preserved; citations per class).
+
+Differences that are deliberate:
+  * forward runs hand-written HIP (bf16 storage, fp32 accumulate) and needs a CUDA/HIP tensor;
+  * nearest upsample + crop_to_factor + centre-crop of the skip + concat is one kernel
+    (ops.upcat) instead of four tensor ops (UNet.py:338-351);
+  * 2-D / 4-D kernels are not built on this path yet: kernel rank 3 only.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import hipnn, ops
+from .utils import NoiseBlock, ParameterizedNoiseBlock
+
+
+def _activation_instance(activation):
+    """UNet.py:41-47: str -> torch.nn name, callable -> instance, None -> Identity (HIP twin where one exists)."""
+    if activation is None:
+        return nn.Identity()
+    if isinstance(activation, str):
+        return hipnn.hip_layer(activation)()
+    return hipnn.hip_layer(activation)()
+
+
+def _conv_cls(dims):
+    if dims == 3:
+        return hipnn.Conv3d
+    if dims == 2:
+        raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet (SURVEY.md §8f rank 1); kernel rank 3 only")
+    raise RuntimeError("%dD convolution not implemented" % dims)  # UNet.py:84-85
+
+
+class ConvPass(nn.Module):
+    """UNet.py:12-117.  conv_pass is an nn.Sequential subclass: conv_pass[i] exposes the same layers."""
+    _raygun_amd = True
+
+    def __init__(self, input_nc, output_nc, kernel_sizes, activation, padding="valid", residual=False,
+                 padding_mode="reflect", norm_layer=None):
+        super().__init__()
+        self.activation = _activation_instance(activation)
+        self.residual = residual
+        self.padding = padding
+        norm_layer = hipnn.hip_layer(norm_layer)
+        layers = []
+        for i, kernel_size in enumerate(kernel_sizes):
+            self.dims = len(kernel_size)
+            conv = _conv_cls(self.dims)
+            layers.append(conv(input_nc, output_nc, tuple(int(k) for k in kernel_size), padding=padding, padding_mode=padding_mode))
+            if residual and i == 0:
+                groups = input_nc if input_nc < output_nc else output_nc
+                # grouped 1x1 map of the residual variant: torch's own op (not on the benchmark path)
+                self.x_init_map = nn.Conv3d(input_nc, output_nc, tuple(np.ones(self.dims, dtype=int)), padding=padding,
+                                            padding_mode=padding_mode, bias=False, groups=groups)
+            if norm_layer is not None:
+                layers.append(norm_layer(output_nc))
+            if not (residual and i == (len(kernel_sizes) - 1)):
+                layers.append(self.activation)
+            input_nc = output_nc
+        self.conv_pass = hipnn.FusedSequential(*layers)
+
+    def crop(self, x, shape):
+        return ops.center_crop(x, tuple(shape))
+
+    @hipnn.scoped
+    def forward(self, x):
+        if not self.residual:
+            return self.conv_pass(x)
+        res = self.conv_pass(x)
+        init_x = ops.enter(hipnn.passthrough(self.x_init_map, x))
+        if self.padding.lower() == "valid":
+            init_x = self.crop(init_x, res.size()[-self.dims:])
+        y = ops.add(init_x, res)
+        a = hipnn.act_of(self.activation)
+        return ops.activation(y, a[0], a[1]) if a is not None else hipnn.passthrough(self.activation, y)
+
+
+class ConvDownsample(nn.Module):
+    """UNet.py:120-188 — strided valid conv + norm + activation."""
+    _raygun_amd = True
+
+    def __init__(self, input_nc, output_nc, kernel_sizes, downsample_factor, activation, padding="valid",
+                 padding_mode="reflect", norm_layer=None):
+        super().__init__()
+        self.activation = _activation_instance(activation)
+        self.padding = padding
+        self.dims = len(kernel_sizes)
+        norm_layer = hipnn.hip_layer(norm_layer)
+        layers = [_conv_cls(self.dims)(input_nc, output_nc, tuple(int(k) for k in kernel_sizes),
+                                       stride=tuple(int(f) for f in downsample_factor), padding="valid", padding_mode=padding_mode)]
+        if norm_layer is not None:
+            layers.append(norm_layer(output_nc))
+        layers.append(self.activation)
+        self.conv_pass = hipnn.FusedSequential(*layers)
+
+    @hipnn.scoped
+    def forward(self, x):
+        return self.conv_pass(x)
+
+
+class MaxDownsample(nn.Module):
+    """UNet.py:191-238 — flexible=True floors sizes that the factor does not divide."""
+    _raygun_amd = True
+
+    def __init__(self, downsample_factor, flexible=True):
+        super().__init__()
+        self.dims = len(downsample_factor)
+        self.downsample_factor = downsample_factor
+        self.flexible = flexible
+        if self.dims not in (3, 4):
+            raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet; 3-D pooling only")
+        f = tuple(int(v) for v in downsample_factor)[-3:]
+        self.down = hipnn.MaxPool3d(f, stride=f)
+
+    @hipnn.scoped
+    def forward(self, x):
+        if self.flexible:
+            try:
+                return self.down(x)
+            except Exception:
+                self.check_mismatch(x.size())
+                raise
+        self.check_mismatch(x.size())
+        return self.down(x)
+
+    def check_mismatch(self, size):
+        for d in range(1, self.dims + 1):
+            if size[-d] % self.downsample_factor[-d] != 0:
+                raise RuntimeError("Can not downsample shape %s with factor %s, mismatch in spatial dimension %d"
+                                   % (size, self.downsample_factor, self.dims - d))
+        return
+
+
+class Upsample(nn.Module):
+    """UNet.py:241-351."""
+    _raygun_amd = True
+
+    def __init__(self, scale_factor, mode=None, input_nc=None, output_nc=None, crop_factor=None,
+                 next_conv_kernel_sizes=None):
+        super().__init__()
+        if crop_factor is not None:
+            assert next_conv_kernel_sizes is not None, "crop_factor and next_conv_kernel_sizes have to be given together"
+        self.crop_factor = crop_factor
+        self.next_conv_kernel_sizes = next_conv_kernel_sizes
+        self.dims = len(scale_factor)
+        self.scale_factor = tuple(int(s) for s in scale_factor)
+        self.mode = mode
+        if self.dims != 3:
+            raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet; 3-D upsampling only")
+        if mode == "transposed_conv":
+            self.up = hipnn.ConvTranspose3d(input_nc, output_nc, kernel_size=self.scale_factor, stride=self.scale_factor)
+        else:
+            if mode != "nearest":
+                raise NotImplementedError(f"raygun_amd.Upsample: mode {mode!r} is not built (nearest / transposed_conv)")
+            self.up = nn.Upsample(scale_factor=self.scale_factor, mode=mode)  # parameter-free; fused in forward
+
+    def target_shape(self, spatial_shape, factor, kernel_sizes):
+        """crop_to_factor (UNet.py:275-325): largest n with n*f + c <= s, c = sum(ks-1)."""
+        convolution_crop = tuple(sum(ks[d] - 1 for ks in kernel_sizes) for d in range(self.dims))
+        ns = (int(math.floor(float(s - c) / f)) for s, c, f in zip(spatial_shape, convolution_crop, factor))
+        target = tuple(n * f + c for n, c, f in zip(ns, convolution_crop, factor))
+        if target != tuple(spatial_shape):
+            assert all(t > c for t, c in zip(target, convolution_crop)), (
+                "Feature map with shape %s is too small to ensure translation equivariance with factor %s and following "
+                "convolutions %s" % (tuple(spatial_shape), factor, kernel_sizes))
+        return target
+
+    def crop(self, x, shape):
+        return ops.center_crop(x, tuple(shape))
+
+    @hipnn.scoped
+    def forward(self, f_left, g_out):
+        if self.mode == "transposed_conv":
+            g_up, factor = self.up(g_out), (1, 1, 1)
+            up_shape = tuple(g_up.shape[-3:])
+        else:
+            g_up, factor = g_out, self.scale_factor
+            up_shape = tuple(a * b for a, b in zip(g_out.shape[-3:], factor))
+        target = up_shape
+        if self.crop_factor is not None:
+            target = self.target_shape(up_shape, self.crop_factor, self.next_conv_kernel_sizes)
+        return ops.upcat(f_left, g_up, factor, target)
+
+
+class UNet(nn.Module):
+    """UNet.py:354-666 — same constructor, attributes (.ndims/.num_levels/.num_heads/.input_nc/.output_nc),
+    module tree (l_conv / l_down / r_up / r_conv) and recursion."""
+    _raygun_amd = True
+
+    def __init__(self, input_nc, ngf, fmap_inc_factor, downsample_factors, kernel_size_down=None, kernel_size_up=None,
+                 activation="ReLU", output_nc=None, num_heads=1, constant_upsample=False, downsample_method="max",
+                 padding_type="valid", residual=False, norm_layer=None, add_noise=False):
+        super().__init__()
+        self.ndims = len(downsample_factors[0])
+        self.num_levels = len(downsample_factors) + 1
+        self.num_heads = num_heads
+        self.input_nc = input_nc
+        self.output_nc = output_nc if output_nc else ngf
+        self.residual = residual
+        if add_noise == "param":
+            self.noise_layer = ParameterizedNoiseBlock()
+        elif add_noise:
+            self.noise_layer = NoiseBlock()
+        else:
+            self.noise_layer = None
+        if kernel_size_down is None:
+            kernel_size_down = [[(3,) * self.ndims, (3,) * self.ndims]] * self.num_levels
+        if kernel_size_up is None:
+            kernel_size_up = [[(3,) * self.ndims, (3,) * self.ndims]] * (self.num_levels - 1)
+
+        # UNet.py:506-522: crop factors for translation equivariance (valid padding only)
+        crop_factors = []
+        factor_product = None
+        for factor in downsample_factors[::-1]:
+            if padding_type.lower() == "valid":
+                factor_product = list(factor) if factor_product is None else [f * ff for f, ff in zip(factor, factor_product)]
+            elif padding_type.lower() == "same":
+                factor_product = None
+            else:
+                raise RuntimeError(f"Invalid padding_type option: {padding_type}")
+            crop_factors.append(factor_product)
+        crop_factors = crop_factors[::-1]
+
+        is_max = downsample_method.lower() == "max"
+        self.l_conv = nn.ModuleList([
+            ConvPass(input_nc if level == 0 else ngf * fmap_inc_factor ** (level - int(is_max)),
+                     ngf * fmap_inc_factor ** level, kernel_size_down[level], activation=activation,
+                     padding=padding_type, residual=self.residual, norm_layer=norm_layer)
+            for level in range(self.num_levels)])
+        self.dims = self.l_conv[0].dims
+
+        if is_max:
+            self.l_down = nn.ModuleList([MaxDownsample(downsample_factors[level]) for level in range(self.num_levels - 1)])
+        elif downsample_method.lower() == "convolve":
+            self.l_down = nn.ModuleList([
+                ConvDownsample(ngf * fmap_inc_factor ** level, ngf * fmap_inc_factor ** (level + 1),
+                               kernel_size_down[level][0], downsample_factors[level], activation=activation,
+                               padding=padding_type, norm_layer=norm_layer)
+                for level in range(self.num_levels - 1)])
+        else:
+            raise RuntimeError(f'Unknown downsampling method {downsample_method}. Use "max" or "convolve" instead.')
+
+        self.r_up = nn.ModuleList([nn.ModuleList([
+            Upsample(downsample_factors[level], mode="nearest" if constant_upsample else "transposed_conv",
+                     input_nc=ngf * fmap_inc_factor ** (level + 1) + (level == 1 and (add_noise is not False)),
+                     output_nc=ngf * fmap_inc_factor ** (level + 1), crop_factor=crop_factors[level],
+                     next_conv_kernel_sizes=kernel_size_up[level])
+            for level in range(self.num_levels - 1)]) for _ in range(num_heads)])
+
+        self.r_conv = nn.ModuleList([nn.ModuleList([
+            ConvPass(ngf * fmap_inc_factor ** level + ngf * fmap_inc_factor ** (level + 1),
+                     ngf * fmap_inc_factor ** level if output_nc is None or level != 0 else output_nc,
+                     kernel_size_up[level], activation=activation, padding=padding_type, residual=self.residual,
+                     norm_layer=norm_layer)
+            for level in range(self.num_levels - 1)]) for _ in range(num_heads)])
+
+    def rec_forward(self, level, f_in):
+        i = self.num_levels - level - 1
+        f_left = self.l_conv[i](f_in)
+        if level == 0:
+            if self.noise_layer is not None:
+                f_left = ops.enter(hipnn.passthrough(self.noise_layer, f_left))
+            fs_out = [f_left] * self.num_heads
+        else:
+            g_in = self.l_down[i](f_left)
+            gs_out = self.rec_forward(level - 1, g_in)
+            fs_right = [self.r_up[h][i](f_left, gs_out[h]) for h in range(self.num_heads)]
+            fs_out = [self.r_conv[h][i](fs_right[h]) for h in range(self.num_heads)]
+        return fs_out
+
+    @hipnn.scoped
+    def forward(self, x):
+        y = self.rec_forward(self.num_levels - 1, ops.enter(x))
+        if self.num_heads == 1:
+            return y[0]
+        return y

@@ -1,0 +1,5 @@
+"""Network architectures (mirror of raygun.torch.networks)."""
+from .NLayerDiscriminator import NLayerDiscriminator
+from .UNet import UNet
+from .ResNet import ResNet
+from .utils import *  # noqa: F401,F403

@@ -1,0 +1,42 @@
+"""torch.optim.Adam semantics on the fused HIP kernel (rg_adam_step): one launch per parameter tensor, state keys
+(step / exp_avg / exp_avg_sq) identical to torch's so optimizer state_dicts interchange.
+Reference call site: optimizers/utils.py:4-9 -> torch.optim.Adam(params, **optim_kwargs) (systems/CycleGAN.py:167-184)."""
+import torch
+
+from ... import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("raygun_amd.FusedAdam: amsgrad is not built")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("raygun_amd.FusedAdam: parameters must live on the GPU (no CPU fallback)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("raygun_amd.FusedAdam: fp32 contiguous master parameters expected")
+                ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
+                               group["weight_decay"], int(st["step"]))
+        return loss

@@ -1,0 +1,169 @@
+"""Config -> networks / model / optimisers / loss wiring — mirror of raygun.torch.systems.BaseSystem
+(reference: systems/BaseSystem.py:20-336).  get_network / setup_* / load_saved_model / checkpoint discovery /
+seeding keep the reference's behaviour; the gunpowder data pipes and Train node are replaced by
+raygun_amd.torch.train (synthetic or in-memory arrays, same call order per step)."""
+import functools
+import logging
+import os
+import random
+import re
+from glob import glob
+
+import numpy as np
+import torch
+
+from ...read_config import read_config
+from .. import networks
+from ..networks.utils import init_weights
+from ... import hipnn, ops
+
+
+class RaygunSequential(hipnn.FusedSequential):
+    """nn.Sequential(net, 1x1 conv[, activation]) of get_network (BaseSystem.py:209-224) as one raygun_amd scope."""
+    _raygun_amd = True
+
+
+class BaseSystem:
+    DEFAULTS = {}
+
+    def __init__(self, default_config=None, config=None):
+        for key, value in (default_config or self.DEFAULTS).items():
+            setattr(self, key, value if not isinstance(value, (dict, list)) else _deepcopy(value))
+        if config is not None:
+            for key, value in read_config(config).items():
+                setattr(self, key, value)
+        if not hasattr(self, "checkpoint_basename"):
+            try:
+                self.checkpoint_basename = os.path.join(self.model_path, self.model_name)
+            except Exception:
+                self.checkpoint_basename = "./models/model"
+        if not hasattr(self, "checkpoint") or self.checkpoint is None:
+            try:
+                self.checkpoint, self.iteration = self._get_latest_checkpoint()
+            except Exception:
+                self.checkpoint = None
+        if getattr(self, "random_seed", None) is not None:
+            self.set_random_seed()
+        self.logger = logging.getLogger(type(self).__name__)
+
+    def set_random_seed(self):
+        """BaseSystem.py:78-83."""
+        if self.random_seed is None:
+            self.random_seed = 42
+        torch.manual_seed(self.random_seed)
+        random.seed(self.random_seed)
+        np.random.seed(self.random_seed)
+
+    def set_device(self, id=0):
+        self.device_id = id
+        os.environ["CUDA_VISIBLE_DEVICES"] = str(id)
+
+    def load_saved_model(self, checkpoint=None, cuda_available=None):
+        """BaseSystem.py:100-123: loads checkpoint['model_state_dict'] (or the bare state_dict) into self.model."""
+        if not hasattr(self, "model"):
+            self.setup_model()
+        if cuda_available is None:
+            cuda_available = torch.cuda.is_available()
+        if checkpoint is None:
+            checkpoint = self.checkpoint
+        else:
+            self.checkpoint = checkpoint
+        if checkpoint is not None:
+            ckpt = torch.load(checkpoint, map_location=None if cuda_available else torch.device("cpu"), weights_only=False)
+            self.model.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)
+        else:
+            self.logger.warning("No saved checkpoint found.")
+
+    def _get_latest_checkpoint(self):
+        """BaseSystem.py:125-143: natural-sort glob of <basename>_checkpoint_<iter>."""
+        basename = self.model_path + self.model_name
+
+        def natural_keys(text):
+            return [int(c) if c.isdigit() else c for c in re.split(r"(\d+)", text)]
+
+        checkpoints = glob(basename + "_checkpoint_*")
+        checkpoints.sort(key=natural_keys)
+        if len(checkpoints) > 0:
+            return checkpoints[-1], int(checkpoints[-1].split("_")[-1])
+        return None, 0
+
+    def get_downsample_factors(self, net_kwargs):
+        """BaseSystem.py:145-161."""
+        if "downsample_factors" not in net_kwargs:
+            down_factor = 2 if "down_factor" not in net_kwargs else net_kwargs.pop("down_factor")
+            num_downs = 3 if "num_downs" not in net_kwargs else net_kwargs.pop("num_downs")
+            net_kwargs.update({"downsample_factors": [(down_factor,) * self.ndims] * (num_downs - 1)})
+        return net_kwargs
+
+    def get_network(self, net_type="unet", net_kwargs=None):
+        """BaseSystem.py:163-242 (pops final_activation/output_nc from the dict it is given, like the reference)."""
+        final_activation = net_kwargs.pop("final_activation") if "final_activation" in net_kwargs else None
+        output_nc = net_kwargs.pop("output_nc") if "output_nc" in net_kwargs else net_kwargs["input_nc"]
+        if isinstance(final_activation, str):
+            final_activation = getattr(torch.nn, final_activation)
+        add_final = True
+        if net_type == "unet":
+            net = networks.UNet(**self.get_downsample_factors(net_kwargs))
+        elif net_type == "resnet":
+            net = networks.ResNet(self.ndims, **net_kwargs)
+        elif net_type == "patchdiscriminator":
+            net_kwargs["norm_layer"] = functools.partial(hipnn.InstanceNorm3d, affine=False, track_running_stats=False)
+            net = networks.NLayerDiscriminator(self.ndims, **net_kwargs)
+            add_final = False
+        elif hasattr(networks, net_type):
+            net = getattr(networks, net_type)(**net_kwargs)
+        else:
+            raise RuntimeError(f"Unknown network type requested: {net_type}")
+        if add_final:
+            if self.ndims != 3:
+                raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet (SURVEY.md §8f rank 1)")
+            layers = [net, hipnn.Conv3d(net_kwargs["ngf"], output_nc, (1,) * self.ndims,
+                                        padding="valid" if "padding_type" not in net_kwargs else net_kwargs["padding_type"])]
+            if final_activation is not None:
+                layers.append(hipnn.hip_layer(final_activation)())  # the reference appends the class itself (:221-222)
+            net = RaygunSequential(*layers)
+        activation = net_kwargs["activation"] if "activation" in net_kwargs else torch.nn.ReLU
+        if activation is not None:
+            init_weights(net, init_type="kaiming", nonlinearity=activation.__class__.__name__.lower())
+        elif net_type == "classic":
+            init_weights(net, init_type="kaiming")
+        else:
+            init_weights(net, init_type="normal", init_gain=0.05)
+        return net
+
+    # -- to be provided by subclasses
+    def setup_networks(self):
+        raise NotImplementedError()
+
+    def setup_model(self):
+        raise NotImplementedError()
+
+    def setup_optimization(self):
+        raise NotImplementedError()
+
+    def setup_datapipes(self):
+        """The reference builds gunpowder graphs here (io/*DataPipe.py, out of scope); raygun_amd systems take arrays."""
+        self.datapipes = {}
+
+    def setup_trainer(self):
+        from ..train import Trainer
+        self.trainer = Trainer(self)
+
+    def build_system(self):
+        """BaseSystem.py:312-318."""
+        self.setup_networks()
+        self.setup_model()
+        self.setup_optimization()
+        self.setup_datapipes()
+        self.setup_trainer()
+
+    def train(self, batches=None):
+        """BaseSystem.py:320-326."""
+        if not hasattr(self, "trainer"):
+            self.build_system()
+        return self.trainer.train(self.num_epochs, batches=batches)
+
+
+def _deepcopy(v):
+    import copy
+    return copy.deepcopy(v)

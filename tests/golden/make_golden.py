@@ -152,6 +152,18 @@ def fx_unet_small():
                    keep_wgrads=["l_conv.0.conv_pass.0.weight"], extra=dict(unet_kwargs=kw2))
 
 
+def fx_smooth():
+    """Networks with smooth activations and strided-conv downsampling: no ReLU/max-pool decisions, so the bf16 GPU
+    gradients can be compared with the fp32 reference at a tight tolerance (see tests/test_networks_gpu.py)."""
+    kw = dict(input_nc=2, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)] * 2, activation="Tanh",
+              downsample_method="convolve", constant_upsample=True)
+    module_fixture("unet_smooth", RN.UNet(**kw), O.UNet(**kw), (1, 2, 62, 62, 62), 111, extra=dict(unet_kwargs=kw))
+    kw2 = dict(kw, constant_upsample=False, num_heads=2)
+    module_fixture("unet_smooth_tconv", RN.UNet(**kw2), O.UNet(**kw2), (1, 2, 62, 62, 62), 112, extra=dict(unet_kwargs=kw2))
+    kg = dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN3, padding_type="same", activation=torch.nn.Tanh)
+    module_fixture("resnet3d_smooth", RN.ResNet(3, **kg), O.ResNet(3, **kg), (1, 1, 24, 24, 24), 113)
+
+
 def _mtlsd_run(model, loss_fn, raw, seed, lr=None):
     affs, lsds = model(raw)
     gt_l = T(synth.uniform(tuple(lsds.shape), seed + 3, 0, 1))
@@ -343,7 +355,7 @@ def fx_structure():
 
 FIXTURES = {
     "convpass": fx_convpass, "maxdown": fx_maxdown, "upsample": fx_upsample, "unet_small": fx_unet_small,
-    "resnet": fx_resnet, "instnorm": fx_instnorm, "misc": fx_misc, "structure": fx_structure,
+    "resnet": fx_resnet, "smooth": fx_smooth, "instnorm": fx_instnorm, "misc": fx_misc, "structure": fx_structure,
     "cyclegan": lambda: fx_cyclegans(False),
     "mtlsd_100": lambda: fx_mtlsd(100, "mtlsd_100", False),
     "mtlsd_196": lambda: fx_mtlsd(196, "mtlsd_196_sampled", True),
