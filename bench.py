@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark (driver contract):  python bench.py --gpus N --steps K --warmup W
+
+Default workload = BASELINE.json's primary metric: 3-D U-Net (MTLSDModel, config "U": ngf 12, x6, 3 levels,
+valid, 259 146 829 parameters, num_affs 3) affinity train step on a synthetic 196^3 volume per GPU:
+forward + WeightedMSELoss_MTLSD + backward + Adam (+ RCCL gradient all-reduce for N > 1), bf16 storage /
+fp32 accumulate.  value = input Mvoxels/s over the whole job (196^3 * N / step time), "scaling": "weak".
+`--workload cyclegan` times the 3-D CycleGAN link train step at 128^3 (BASELINE's second figure, ms/step).
+
+One JSON line is printed by rank 0, carrying `roofline` (dominant conv kernel, HIP events on the launch stream,
+algorithmic FLOPs = 2*rows*taps*Cin*Cout) and `cpu_baseline` (the oracle's plain-PyTorch CPU restatement on a
+bounded sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: 256 CU x 4096 FLOP/clk x 2.4 GHz)
+UNET_FLOP_PER_STEP = 19.47e12  # 3 x 6.4925 TFLOP - 4.7 GFLOP (no dgrad into the raw input)
+CYC_FLOP_PER_STEP = 94.3e12    # SURVEY.md §8a train-step FLOP budget (link, identity lambda 0, 128^3)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan"])
+    ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 for unet, 128 for cyclegan)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_unet(dev, size, seed):
+    from raygun_amd import synth
+    from raygun_amd.torch.models import MTLSDModel
+    from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
+    from raygun_amd.torch.optimizers import FusedAdam
+    torch.manual_seed(1234)  # identical random-init weights on every rank
+    with torch.device(dev):
+        model = MTLSDModel(num_affs=3)
+    loss_fn = WeightedMSELoss_MTLSD()
+    opt = FusedAdam(model.parameters(), lr=0.5e-4)
+    raw = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42 + seed)).to(dev)
+    out = 8 * ((size - 92) // 8)
+    gt_a = torch.from_numpy(synth.uniform((1, 3, out, out, out), 142 + seed, 0, 1)).to(dev)
+    gt_l = torch.from_numpy(synth.uniform((1, 10, out, out, out), 242 + seed, 0, 1)).to(dev)
+    w_a, w_l = torch.ones_like(gt_a), torch.ones_like(gt_l)
+
+    def step(sync):
+        opt.zero_grad(set_to_none=True)
+        affs, lsds = model(raw)
+        loss = loss_fn(lsds, gt_l, w_l, affs, gt_a, w_a)
+        loss.backward()
+        sync([p for p in model.parameters()])
+        opt.step()
+        return loss
+
+    return step, dict(model="MTLSDModel(UNet ngf12 x6 3-level valid)+WeightedMSELoss_MTLSD+Adam", params=259146829)
+
+
+def build_cyclegan(dev, size, seed):
+    import functools
+    from raygun_amd import synth
+    from raygun_amd.torch.systems import CycleGAN
+    torch.manual_seed(1234)
+    cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
+               gnet_kwargs=dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=functools.partial(torch.nn.InstanceNorm3d),
+                                padding_type="same"),
+               dnet_kwargs=dict(input_nc=1, ngf=64, n_layers=3, kw=4), loss_type="link",
+               loss_kwargs={"g_lambda_dict": {s: {"l1_loss": {"cycled": 10, "identity": 0}, "gan_loss": {"fake": 1, "cycled": 0}} for s in "AB"}},
+               random_seed=None)
+    s = CycleGAN(cfg)
+    s.setup_networks()
+    for n in (s.netG1, s.netG2, s.netD1, s.netD2):
+        n.to(dev)
+    s.setup_model()
+    holder = {}
+    s.setup_optimization(grad_sync=lambda params: holder["sync"](params))
+    A = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42 + seed)).to(dev)
+    B = torch.from_numpy(synth.uniform((1, 1, size, size, size), 1042 + seed)).to(dev)
+
+    def step(sync):
+        holder["sync"] = sync
+        s.optimizer.zero_grad()
+        fB, cB, fA, cA = s.model(real_A=A, real_B=B)
+        loss = s.loss(A, fA, cA, B, fB, cB)
+        loss.backward()
+        s.optimizer.step()
+        return loss
+
+    return step, dict(model="CycleGAN link: ResNet(ngf64,6 blocks,2 down,IN)+PatchD(ngf64,3 layers) lsgan", params=71848196)
+
+
+def cpu_baseline(workload, size):
+    """The oracle (plain PyTorch fp32 restatement) timed on this host's cores for one step on a bounded sample."""
+    from oracle import torch_ref as O
+    from raygun_amd import synth
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    if workload == "unet":
+        m = O.MTLSDModel()
+        lf = O.WeightedMSELoss_MTLSD()
+        raw = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42))
+        out = 8 * ((size - 92) // 8)
+        ga = torch.from_numpy(synth.uniform((1, 3, out, out, out), 142, 0, 1))
+        gl = torch.from_numpy(synth.uniform((1, 10, out, out, out), 242, 0, 1))
+        opt = torch.optim.Adam(m.parameters(), lr=0.5e-4)
+        t0 = time.time()
+        O.mtlsd_step(m, lf, opt, raw, gl, torch.ones_like(gl), ga, torch.ones_like(ga))
+        dt = time.time() - t0
+        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
+                    sample=f"1 step (fwd+loss+bwd+Adam) of the CPU restatement at {size}^3 (torch {torch.__version__} fp32, oneDNN), {dt:.1f} s")
+    import functools
+    IN3 = functools.partial(torch.nn.InstanceNorm3d)
+    model, loss, _ = O.build_cyclegan(3, dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same"),
+                                      dict(input_nc=1, ngf=64, n_layers=3, kw=4), g_lr=1e-5, d_lr=1e-5, betas=(0.9, 0.999))
+    A = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42)); B = torch.from_numpy(synth.uniform((1, 1, size, size, size), 1042))
+    t0 = time.time()
+    O.cyclegan_step(model, loss, A, B)
+    dt = time.time() - t0
+    return dict(value=dt * 1e3, unit="ms/step", cores=cores, kind="port",
+                sample=f"1 link train step of the CPU restatement at {size}^3 (work ratio to 128^3: {(128 / size) ** 3:.0f}x), {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    from raygun_amd import ops, parallel
+    rank, local, world = parallel.init_from_env()
+    if world != max(1, a.gpus) and rank == 0:
+        print(f"[bench] warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    size = a.size or (196 if a.workload == "unet" else 128)
+    step, info = (build_unet if a.workload == "unet" else build_cyclegan)(dev, size, seed=rank)
+    sync = parallel.GradSync()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(sync)
+    barrier()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    ms = dt / a.steps * 1e3
+    kernels = {k: dict(launches=v["launches"] // a.steps, ms_per_step=v["ms"] / a.steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0)
+               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        launches_per_step=dom[1]["launches"] // a.steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
+    flop = (UNET_FLOP_PER_STEP if a.workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if a.workload == "unet" else 128)) ** 3
+    res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if a.workload == "unet" else "CycleGAN 128^3 train-step ms",
+               value=round(size ** 3 * world / (dt / a.steps) / 1e6, 3) if a.workload == "unet" else round(ms, 3),
+               unit="Mvoxels/s" if a.workload == "unet" else "ms/step", n_gpus=world, steps=a.steps, warmup=a.warmup,
+               ms_per_step=round(ms, 3), higher_is_better=a.workload == "unet", scaling="weak", vs_baseline=None, dtype="bf16",
+               data="synthetic",
+               config=dict(workload=f"{a.workload} {size}^3 batch 1 per GPU, {info['model']}", params=info["params"],
+                           parallelism=f"dp{world}", precision="bf16 storage, fp32 accumulate, fp32 master weights + Adam state"),
+               step_tflops=round(flop / (dt / a.steps) / 1e12 * 1.0, 2), step_frac_of_mfma_peak=round(flop / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+               roofline=roofline, kernels=kernels)
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_size or (132 if a.workload == "unet" else 32))
+        except Exception as e:  # the baseline is reported, never the product path
+            res["cpu_baseline"] = dict(error=repr(e))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,8 @@ typedef struct {
 
 int rg_version(void);
 const char* rg_last_error_string(void);
+/* name (template instantiation) of the main kernel launched by this thread's last conv/wgrad call — profiling aid */
+const char* rg_last_kernel_name(void);
 
 /* ---- layout conversion (torch .to(memory_format)/.float() around the nets: torch/predict/worker.py:101-110,146-149)
  * src: any dtype in {bf16,f32,u8}, any strides.  dst: bf16 or f32, any strides.  dst_lanes >= C: channel lanes

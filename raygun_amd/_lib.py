@@ -41,6 +41,7 @@ _I3 = C.c_int32 * 3
 _SIGS = {
     "rg_version": (C.c_int, []),
     "rg_last_error_string": (C.c_char_p, []),
+    "rg_last_kernel_name": (C.c_char_p, []),
     "rg_copy_convert": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),
     "rg_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, _P(rg_pack_params), C.c_void_p]),

@@ -189,6 +189,7 @@ template <int BM, int FN>
 static void launch_igemm(const IgemmArgs& a, hipStream_t s) {
   constexpr int BN = FN * 16;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.cout_lanes + BN - 1) / BN));
+  rg_set_kernel_name("igemm_kernel<%d,%d>", BM, FN);
   hipLaunchKernelGGL((igemm_kernel<BM, FN>), grid, dim3(256), 0, s, a);
 }
 

@@ -10,6 +10,11 @@ void rg_set_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* rg_last_error_string(void) { return g_err; }
+static thread_local char g_kname[128] = "";
+void rg_set_kernel_name(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_kname, sizeof(g_kname), fmt, ap); va_end(ap);
+}
+extern "C" const char* rg_last_kernel_name(void) { return g_kname; }
 extern "C" int rg_version(void) { return 100; }
 
 static inline int grid_for(long n, int block = 256, int cap = 1 << 20) {

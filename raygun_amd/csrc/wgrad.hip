@@ -221,6 +221,7 @@ template <int FA, int FB, int WA, int WB>
 static void launch_wgrad(const WgradArgs& a, hipStream_t s) {
   const int nta = (a.A + FA * 16 - 1) / (FA * 16), ntb = (a.B + FB * 16 - 1) / (FB * 16);
   dim3 grid(nta * ntb, a.TD * a.TH * a.TW, a.nsplit);
+  rg_set_kernel_name("wgrad_kernel<%d,%d,%d,%d>", FA, FB, WA, WB);
   hipLaunchKernelGGL((wgrad_kernel<FA, FB, WA, WB>), grid, dim3(WA * WB * 64), 0, s, a);
 }
 

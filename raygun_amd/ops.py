@@ -175,10 +175,50 @@ def _conv_params(R, T, rstride, tbase, tstep, ostride, ooffset, cout, act="none"
     return p
 
 
+_prof = None
+
+
+def profile_start():
+    """Start recording a HIP-event pair (on torch's current stream = the launch stream) around every conv kernel."""
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    """-> {kernel name: dict(launches, ms, flops)} ; algorithmic flops = 2*rows*taps*Cin*Cout per launch."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, flops, e0, e1 in rec or []:
+        d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        d["launches"] += 1
+        d["ms"] += e0.elapsed_time(e1)
+        d["flops"] += flops
+    return out
+
+
+def _timed(flops, fn):
+    if _prof is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _prof.append((_lib.lib().rg_last_kernel_name().decode(), flops, e0, e1))
+    return r
+
+
+def _conv_flops(p, n, cin, cout):
+    return 2.0 * n * p.R[0] * p.R[1] * p.R[2] * p.T[0] * p.T[1] * p.T[2] * cin * cout
+
+
 def _igemm(x, wp, bias, y, p):
     bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
-    _lib.check(_lib.lib().rg_conv3d_igemm(C.byref(desc(x)), C.c_void_p(wp.data_ptr()), bptr, C.byref(desc(y)), C.byref(p),
-                                          _stream()), "rg_conv3d_igemm")
+    dx, dy = desc(x), desc(y)
+    _timed(_conv_flops(p, x.shape[0], x.shape[1], y.shape[1]),
+           lambda: _lib.check(_lib.lib().rg_conv3d_igemm(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
+                                                         _stream()), "rg_conv3d_igemm"))
 
 
 def _wgrad(g, x, p, shape):
@@ -189,8 +229,9 @@ def _wgrad(g, x, p, shape):
     if nbytes < 0:
         _lib.check(-1, "rg_conv3d_wgrad_workspace_bytes")
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
-    _lib.check(_lib.lib().rg_conv3d_wgrad(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p), 0,
-                                          C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad")
+    _timed(_conv_flops(p, g.shape[0], x.shape[1], g.shape[1]),
+           lambda: _lib.check(_lib.lib().rg_conv3d_wgrad(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p), 0,
+                                                         C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad"))
     return dw
 
 

@@ -1,0 +1,75 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI on ROCm,
+"gloo" for the CPU tests).  The reference has no distributed code at all (single GPU, no DDP);
+this is the build's own component, defined by "N-GPU result == 1-GPU result on the concatenated batch"
+(SURVEY.md §8e): gradients are summed over ranks and divided by world size right before each optimiser step.
+
+Samples are independent (InstanceNorm / no norm => no cross-sample statistics), so there is no other exchange.
+Gradients are reduced tensor by tensor, largest first, as asynchronous all-reduces that RCCL pipelines over
+the 7 xGMI links; flattening into buckets would only add a 1 GB copy for the U-Net (70 % of whose parameters
+sit in one 725 MB tensor).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradSync:
+    """Callable(list_of_params): average .grad over all ranks (no-op for world size 1)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, params):
+        ws = world_size()
+        if ws == 1:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        grads.sort(key=lambda g: -g.numel())
+        handles = []
+        for g in grads:
+            if not g.is_contiguous():
+                raise RuntimeError("raygun_amd.GradSync: gradients must be contiguous")
+            handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()
+        inv = 1.0 / ws
+        torch._foreach_mul_(grads, inv)
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank `src`'s weights."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def shard_blocks(n_blocks, rank=None, world=None):
+    """Static contiguous partition of a block list over ranks (block-wise predict: no collective)."""
+    rank = dist.get_rank() if rank is None and world_size() > 1 else (rank or 0)
+    world = world_size() if world is None else world
+    per = (n_blocks + world - 1) // world
+    return range(min(n_blocks, rank * per), min(n_blocks, (rank + 1) * per))
