@@ -39,4 +39,6 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("raygun_amd.FusedAdam: fp32 contiguous master parameters expected")
                 ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
                                group["weight_decay"], int(st["step"]))
+                # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
+                torch.autograd.graph.increment_version(p)
         return loss

@@ -233,7 +233,7 @@ def fx_instnorm():
     save("instnorm3d", y=y.detach().numpy(), gx=xi.grad.numpy())
 
 
-def _cyc_cfg(nd, gk, dk, loss_type, lr=2e-3):
+def _cyc_cfg(nd, gk, dk, loss_type, lr=5e-4):
     return dict(common_voxel_size=[1] * 3, ndims=nd, gnet_type="resnet", gnet_kwargs=gk, dnet_kwargs=dk,
                 loss_type=loss_type, loss_kwargs={},
                 g_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr))
@@ -246,7 +246,7 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2):
     rs = RCycleGAN(cfg)
     rs.setup_networks(); rs.setup_model(); rs.setup_optimization()
     model, loss, opts = O.build_cyclegan(nd, dict(gk), dict(dk), split=(loss_type == "split"),
-                                         g_lr=2e-3, d_lr=2e-3, betas=(0.5, 0.999), loss_kwargs=loss_kwargs, init=False)
+                                         g_lr=5e-4, d_lr=5e-4, betas=(0.5, 0.999), loss_kwargs=loss_kwargs, init=False)
     nets_r = dict(G1=rs.netG1, G2=rs.netG2, D1=rs.netD1, D2=rs.netD2)
     nets_o = dict(G1=model.netG1, G2=model.netG2, D1=loss.netD1, D2=loss.netD2)
     for i, k in enumerate(nets_r):
@@ -273,7 +273,7 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2):
         wsum[k] = [float(sum(p.double().sum() for p in nets_r[k].parameters())),
                    float(sum(p.double().abs().sum() for p in nets_r[k].parameters()))]
     save(tag, loss_dicts=json.dumps(recs), weight_sums=json.dumps(wsum), fake_B=fB.detach().numpy(),
-         meta=json.dumps(dict(shape=list(shape), loss_type=loss_type, lr=2e-3, betas=[0.5, 0.999], iters=iters,
+         meta=json.dumps(dict(shape=list(shape), loss_type=loss_type, lr=5e-4, betas=[0.5, 0.999], iters=iters,
                               gk={k: str(v) for k, v in gk.items()}, dk={k: str(v) for k, v in dk.items()},
                               state_keys_model=list(rs.model.state_dict().keys()))))
 

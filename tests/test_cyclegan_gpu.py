@@ -1,0 +1,85 @@
+"""GPU parity of the CycleGAN train step (LinkCycleLoss / SplitCycleLoss own backward + optimiser steps) against the
+loss_dict trajectories recorded from the REFERENCE system (tests/golden/cyclegan_step_*_3d32.npz, 2 iterations,
+Adam lr 5e-4 so that iteration 1 depends on the whole of iteration 0's backward + update).
+
+Tolerance: iteration 0 is forward-only (<= 2 % per loss term); iteration 1 sees weights updated by bf16 gradients
+(Adam normalises the step, so sign-level agreement matters most): <= 6 % of max(|term|, |its change over the update|)."""
+import functools
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from raygun_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build_system(loss_type, loss_kwargs=None):
+    from raygun_amd.torch.systems import CycleGAN
+    IN3 = functools.partial(torch.nn.InstanceNorm3d)
+    cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
+               gnet_kwargs=dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN3, padding_type="same"),
+               dnet_kwargs=dict(input_nc=1, ngf=8, n_layers=3, kw=4), loss_type=loss_type, loss_kwargs=loss_kwargs or {},
+               g_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4))
+    s = CycleGAN(cfg)
+    s.setup_networks()
+    dev = torch.device("cuda")
+    for i, k in enumerate(["netG1", "netG2", "netD1", "netD2"]):
+        net = getattr(s, k)
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i))
+        net.to(dev)
+    s.setup_model()
+    s.setup_optimization()
+    return s, dev
+
+
+def run_steps(s, dev, iters):
+    recs = []
+    for it in range(iters):
+        A = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 90 + 2 * it)).to(dev)
+        B = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 91 + 2 * it)).to(dev)
+        s.optimizer.zero_grad()
+        fB, cB, fA, cA = s.model(real_A=A, real_B=B)
+        tot = s.loss(A, fA, cA, B, fB, cB)
+        tot.backward()
+        s.optimizer.step()
+        recs.append({k: float(v) for k, v in s.loss.loss_dict.items()})
+    return recs, fB
+
+
+@pytest.mark.parametrize("fixture,loss_type,ident", [("cyclegan_step_link_3d32", "link", False),
+                                                     ("cyclegan_step_split_3d32", "split", False),
+                                                     ("cyclegan_step_link_identity_3d32", "link", True)])
+def test_train_step_loss_trajectory(fixture, loss_type, ident):
+    fx = np.load(os.path.join(G, fixture + ".npz"))
+    ref = json.loads(str(fx["loss_dicts"]))
+    lk = None
+    if ident:
+        lk = {"g_lambda_dict": {s: {"l1_loss": {"cycled": 10, "identity": 0.5}, "gan_loss": {"fake": 1, "cycled": 0}} for s in "AB"}}
+    s, dev = build_system(loss_type, lk)
+    assert list(s.model.state_dict().keys()) == json.loads(str(fx["meta"]))["state_keys_model"]
+    recs, fB = run_steps(s, dev, len(ref))
+    for it, (mine, theirs) in enumerate(zip(recs, ref)):
+        assert set(mine) == set(theirs)
+        tol = 0.02 if it == 0 else 0.06
+        for k in theirs:
+            scale = max(abs(theirs[k]), 0.05, abs(theirs[k] - ref[0][k]))  # value, or its change over the update if larger
+            assert abs(mine[k] - theirs[k]) <= tol * scale, (it, k, mine[k], theirs[k])
+    # all four nets are trainable again after the step (SplitCycleLoss.py:148 / LinkCycleLoss.py:130-133)
+    for net in (s.netG1, s.netG2, s.netD1, s.netD2):
+        assert all(p.requires_grad for p in net.parameters())
+    a = fB.detach().float().cpu().numpy().astype(np.float64)
+    b = fx["fake_B"].astype(np.float64)
+    assert np.sqrt(((a - b) ** 2).sum()) / np.sqrt((b ** 2).sum()) <= (0.1 if len(ref) > 1 else 0.03)
+
+
+def test_total_loss_backward_is_noop_and_weights_move():
+    s, dev = build_system("link")
+    w0 = [p.detach().clone() for p in s.netG1.parameters()]
+    recs, _ = run_steps(s, dev, 1)
+    moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip(s.netG1.parameters(), w0))
+    assert moved > 0 and all(np.isfinite(v) for v in recs[0].values())
