@@ -21,7 +21,7 @@ class rg_tensor(C.Structure):
 
 class rg_pack_params(C.Structure):
     _fields_ = [("dim0", C.c_int32), ("dim1", C.c_int32), ("K", C.c_int32 * 3), ("swap", C.c_int32),
-                ("k0", C.c_int32 * 3), ("kstep", C.c_int32 * 3), ("ntap", C.c_int32 * 3)]
+                ("k0", C.c_int32 * 3), ("kstep", C.c_int32 * 3), ("ntap", C.c_int32 * 3), ("red_align", C.c_int32)]
 
 
 class rg_conv_params(C.Structure):
@@ -43,6 +43,7 @@ _SIGS = {
     "rg_last_error_string": (C.c_char_p, []),
     "rg_last_kernel_name": (C.c_char_p, []),
     "rg_copy_convert": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "rg_conv3d_kalign": (C.c_int, [C.c_int, C.c_int]),
     "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),
     "rg_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
     "rg_conv3d_igemm": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p]),

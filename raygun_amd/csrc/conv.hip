@@ -193,6 +193,18 @@ static void launch_igemm(const IgemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((igemm_kernel<BM, FN>), grid, dim3(256), 0, s, a);
 }
 
+extern "C" int rg_conv3d_kalign(int cin, int cout);
+int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p,
+                     const void* zeros, hipStream_t st);
+__device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
+static const void* zero_page() {
+  static const void* cache[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!cache[dev]) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(rg_zero_page)) != hipSuccess) return nullptr; cache[dev] = p; }
+  return cache[dev];
+}
+
 extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                                const rg_conv_params* p, rg_stream s) {
   CL5 X, Y;
@@ -206,6 +218,13 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
     if (p->R[d] <= 0 || p->T[d] <= 0) RG_FAIL(RG_ERR_BAD_SHAPE, "conv: empty row grid / tap lattice");
     const long last = (long)(p->R[d] - 1) * p->ostride[d] + p->ooffset[d];
     if (p->ooffset[d] < 0 || last >= Yd[d]) RG_FAIL(RG_ERR_BAD_SHAPE, "conv: row grid writes outside y along dim %d (last %ld, size %d)", d, last, Yd[d]);
+  }
+  if (rg_conv3d_kalign(X.C, p->cout) == 64) {
+    const void* z = zero_page();
+    if (!z) RG_FAIL(RG_ERR_HIP, "conv: cannot resolve the zero page symbol");
+    rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    RG_CHECK_LAUNCH();
+    return RG_OK;
   }
   IgemmArgs a;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;

@@ -90,8 +90,9 @@ __global__ void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params 
     out[i] = f2bf(v);
   }
 }
+static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : 32; }
 static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
-  if (!p || p->dim0 <= 0 || p->dim1 <= 0) return -1;
+  if (!p || p->dim0 <= 0 || p->dim1 <= 0 || (p->red_align != 0 && p->red_align != 32 && p->red_align != 64)) return -1;
   for (int d = 0; d < 3; ++d) {
     if (p->K[d] <= 0 || p->ntap[d] <= 0 || p->k0[d] < 0 || p->kstep[d] <= 0) return -1;
     if (p->k0[d] + p->kstep[d] * (p->ntap[d] - 1) >= p->K[d]) return -1;
@@ -102,12 +103,12 @@ static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
 extern "C" int64_t rg_pack_weights_bytes(const rg_pack_params* p) {
   int rows, red;
   if (pack_dims(p, &rows, &red)) return -1;
-  return (int64_t)round_up(rows, 16) * p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, 32) * 2;
+  return (int64_t)round_up(rows, 16) * p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, pack_align(p)) * 2;
 }
 extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_params* p, rg_stream s) {
   int rows, red;
   if (!w || !packed || pack_dims(p, &rows, &red)) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: bad params");
-  const int rows16 = round_up(rows, 16), red32 = round_up(red, 32);
+  const int rows16 = round_up(rows, 16), red32 = round_up(red, pack_align(p));
   const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
   RG_CHECK_LAUNCH();

@@ -43,9 +43,15 @@ def lanes_of(c):
     return (c + 7) // 8 * 8
 
 
+def voxel_stride_of(c):
+    """Elements between consecutive voxels: wide tensors are padded to whole 128-byte lines so that every 64-channel
+    slice the conv kernels DMA (8 lanes x 16 B) is exactly one cache line instead of straddling two."""
+    return lanes_of(c) if c < 64 else (c + 63) // 64 * 64
+
+
 def cl_empty(n, c, d, h, w, device):
     """Uninitialised channels-last bf16 activation (every kernel writes all lanes incl. zero pad lanes)."""
-    buf = torch.empty((n, d, h, w, lanes_of(c)), dtype=torch.bfloat16, device=device)
+    buf = torch.empty((n, d, h, w, voxel_stride_of(c)), dtype=torch.bfloat16, device=device)
     return buf.permute(0, 4, 1, 2, 3)[:, :c]
 
 
@@ -156,6 +162,8 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     for i in range(3):
         p.K[i], p.k0[i], p.kstep[i], p.ntap[i] = K[i], k0[i], kstep[i], nt[i]
     p.swap = int(swap)
+    rows, red = (wd.shape[1], wd.shape[0]) if swap else (wd.shape[0], wd.shape[1])
+    p.red_align = _lib.lib().rg_conv3d_kalign(int(red), int(rows))
     nbytes = _lib.lib().rg_pack_weights_bytes(C.byref(p))
     if nbytes < 0:
         raise RuntimeError("raygun_amd.pack_weights: bad packing parameters")

@@ -68,6 +68,14 @@ CONV_CASES = [
     (4, 6, 7, 1, 0, (9, 9, 10), "none"),
     (200, 24, 3, 1, 0, (5, 5, 6), "relu"),
     (6, 4, (3, 1, 2), (2, 1, 1), (1, 0, 0), (8, 6, 7), "none"),
+    # wide-channel kernel (igemm2: LDS-DMA ring, BK=64): Cin >= 64 and Cout >= 48
+    (96, 160, 3, 1, 1, (6, 7, 8), "relu"),
+    (64, 64, 3, 2, 1, (9, 10, 12), "none"),
+    (72, 80, 3, 1, 0, (7, 8, 9), "leaky"),
+    (136, 48, 1, 1, 0, (5, 6, 7), "none"),
+    (144, 432, 3, 1, 0, (6, 6, 7), "relu"),
+    (64, 72, 7, 1, 0, (9, 9, 9), "none"),
+    (128, 64, 4, 2, 1, (10, 10, 10), "leaky"),
 ]
 
 
@@ -91,6 +99,8 @@ CONVT_CASES = [
     (4, 4, 2, 2, 0, 0, (5, 5, 5), "none"),
     (6, 10, 3, 1, 1, 0, (5, 6, 4), "none"),
     (4, 3, 3, 2, 0, 0, (4, 5, 6), "none"),
+    (128, 64, 3, 2, 1, 1, (5, 6, 7), "relu"),
+    (64, 80, 3, 2, 1, 1, (6, 5, 4), "none"),
 ]
 
 
