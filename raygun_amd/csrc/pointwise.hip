@@ -158,12 +158,19 @@ __global__ void act_bwd_bias_kernel(CL5 gy, CL5 y, CL5 g, float* partial, int ac
     for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * gy.lanes + grp * 8 + k] = sum[k];
   }
 }
+// out[c] = sum_b partial[b][c]: one workgroup per channel, fixed-order tree (deterministic)
 __global__ void reduce_partials_kernel(const float* partial, float* out, int nblk, int lanes, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[256];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * lanes + c];
-  out[c] = s;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * lanes + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = red[0];
 }
 static void abb_plan(const CL5& t, int* gx, int* gy, int* vpb, int* nblk) {
   const int G8 = t.lanes / 8;
@@ -199,7 +206,7 @@ extern "C" int rg_act_bwd_bias(const rg_tensor* gy, const rg_tensor* y, const rg
   hipLaunchKernelGGL(act_bwd_bias_kernel, grid, block, 256 * 8 * sizeof(float), (hipStream_t)s, GY, Y, G, partial, act, slope, vpb, has_y);
   RG_CHECK_LAUNCH();
   if (db) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((GY.C + 63) / 64), dim3(64), 0, (hipStream_t)s, partial, db, nblk, GY.lanes, GY.C);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(GY.C), dim3(256), 0, (hipStream_t)s, partial, db, nblk, GY.lanes, GY.C);
     RG_CHECK_LAUNCH();
   }
   return RG_OK;

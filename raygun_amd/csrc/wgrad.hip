@@ -34,14 +34,15 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
   constexpr int TA = FA * 16, TB = FB * 16;
   constexpr int SA = wg_pad(TA), SB = wg_pad(TB);
   constexpr int CA = TA / 8, CB = TB / 8;       // 16-byte chunks per row
-  constexpr int NCH = 32 * (CA + CB);
+  constexpr int KR = 32;  // rows per barrier step (64 measured slower: 199 vs 326 TFLOP/s on 3024->432, register pressure)
+  constexpr int NCH = KR * (CA + CB);
   constexpr int PER_T = (NCH + NT - 1) / NT;
   constexpr int IA = FA / WA, IB = FB / WB;     // fragments per wave
   static_assert(FA % WA == 0 && FB % WB == 0, "wave layout must divide the tile");
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 32 * (SA + SB)];
-  __shared__ RowInfo ri[2][32];
-  bf16_t* Gs = lds;                  // [2][32][SA]
-  bf16_t* Xs = lds + 2 * 32 * SA;    // [2][32][SB]
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * KR * (SA + SB)];
+  __shared__ RowInfo ri[2][KR];
+  bf16_t* Gs = lds;                  // [2][KR][SA]
+  bf16_t* Xs = lds + 2 * KR * SA;    // [2][KR][SB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave / WB, wb = wave % WB;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
   const int od = a.tb[0] + kd * a.ts[0], oh = a.tb[1] + kh * a.ts[1], ow = a.tb[2] + kw * a.ts[2];
   const long mbeg = (long)blockIdx.z * a.rows_per_split;
   long mend = mbeg + a.rows_per_split; if (mend > a.M) mend = a.M;
-  const int nsteps = (int)((mend - mbeg + 31) / 32);
+  const int nsteps = (int)((mend - mbeg + KR - 1) / KR);
 
   f32x4 acc[IA][IB];
 #pragma unroll
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < IB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto rowinfo = [&](int step) {
-    if (tid < 32) {
-      const long m = mbeg + (long)step * 32 + tid;
+    if (tid < KR) {
+      const long m = mbeg + (long)step * KR + tid;
       RowInfo r; r.goff = -1; r.xoff = -1;
       if (m < mend) {
         long t = m;
@@ -84,12 +85,12 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < PER_T; ++i) {
       const int q = tid + NT * i;
       bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (q < 32 * CA) {
+      if (q < KR * CA) {
         const int row = q / CA, c = a0 + (q % CA) * 8;
         const long off = ri[step & 1][row].goff;
         if (off >= 0 && c < a.alanes) v = *(const bf16x8*)(a.g + off + c);
       } else if (q < NCH) {
-        const int q2 = q - 32 * CA;
+        const int q2 = q - KR * CA;
         const int row = q2 / CB, c = b0 + (q2 % CB) * 8;
         const RowInfo r = ri[step & 1][row];
         if (r.goff >= 0 && r.xoff >= 0 && c < a.blanes) v = *(const bf16x8*)(a.x + r.xoff + c);
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
       const int q = tid + NT * i;
-      if (q < 32 * CA) {
-        *(bf16x8*)(Gs + (buf * 32 + q / CA) * SA + (q % CA) * 8) = regs[i];
+      if (q < KR * CA) {
+        *(bf16x8*)(Gs + (buf * KR + q / CA) * SA + (q % CA) * 8) = regs[i];
       } else if (q < NCH) {
-        const int q2 = q - 32 * CA;
-        *(bf16x8*)(Xs + (buf * 32 + q2 / CB) * SB + (q2 % CB) * 8) = regs[i];
+        const int q2 = q - KR * CA;
+        *(bf16x8*)(Xs + (buf * KR + q2 / CB) * SB + (q2 % CB) * 8) = regs[i];
       }
     }
   };
@@ -123,26 +124,29 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
     if (s + 1 < nsteps) rowinfo(s + 1);
     __syncthreads();
     if (s + 1 < nsteps) gload(s + 1);
-    bf16x8 gf[IA], xf[IB];
 #pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      const bf16_t* base = Gs + (buf * 32 + 8 * fg + fq) * SA + (wa * IA + i) * 16 + 4 * fp;
-      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
-      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SA));
-      gf[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int sub = 0; sub < KR / 32; ++sub) {
+      bf16x8 gf[IA], xf[IB];
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bf16_t* base = Gs + (buf * KR + sub * 32 + 8 * fg + fq) * SA + (wa * IA + i) * 16 + 4 * fp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SA));
+        gf[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < IB; ++j) {
+        const bf16_t* base = Xs + (buf * KR + sub * 32 + 8 * fg + fq) * SB + (wb * IB + j) * 16 + 4 * fp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SB));
+        xf[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < IB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < IB; ++j) {
-      const bf16_t* base = Xs + (buf * 32 + 8 * fg + fq) * SB + (wb * IB + j) * 16 + 4 * fp;
-      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
-      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SB));
-      xf[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#pragma unroll
-    for (int i = 0; i < IA; ++i)
-#pragma unroll
-      for (int j = 0; j < IB; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
   }
 
   const int ntaps = a.TD * a.TH * a.TW;
@@ -160,17 +164,261 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dw[a][b][tap] (+)= sum_s part[s][a][tap][b]
+// dw[a][b][tap] (+)= sum_s part[s][a][tap][b].  One workgroup = one `a` x 64 consecutive `b`: the [tap][64] slab is read
+// with coalesced 256-byte rows, transposed through LDS and written as one contiguous run of 64*ntaps floats.
+// out[j][i] = sum_{s in [j*R, (j+1)*R)} part[s][i]: folds many row splits (thin layers use up to 2048) before the finish
+#define WF_FOLD 32
+__global__ void wgrad_fold_kernel(const float* part, float* out, long total, int nsplit) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int s0 = blockIdx.y * WF_FOLD;
+  const int s1 = s0 + WF_FOLD < nsplit ? s0 + WF_FOLD : nsplit;
+  float v = 0.f;
+  for (int s = s0; s < s1; ++s) v += part[s * total + i];
+  out[blockIdx.y * total + i] = v;
+}
+#define WF_MAXTAPS 64
 __global__ void wgrad_finish_kernel(const float* part, float* dw, int A, int B, int ntaps, int nsplit, int accumulate) {
+  __shared__ float tile[WF_MAXTAPS][65];
+  const int nbt = (B + 63) / 64;
+  const int aa = blockIdx.x / nbt, b0 = (blockIdx.x % nbt) * 64;
   const long total = (long)A * ntaps * B;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += part[s * total + i];
-    const int b = (int)(i % B); long t = i / B;
-    const int tap = (int)(t % ntaps); const int aa = (int)(t / ntaps);
-    const long o = ((long)aa * B + b) * ntaps + tap;
-    dw[o] = accumulate ? dw[o] + v : v;
+  for (int t0 = 0; t0 < ntaps; t0 += WF_MAXTAPS) {
+    const int nt = ntaps - t0 < WF_MAXTAPS ? ntaps - t0 : WF_MAXTAPS;
+    for (int i = threadIdx.x; i < nt * 64; i += blockDim.x) {
+      const int t = i / 64, b = i % 64;
+      float v = 0.f;
+      if (b0 + b < B) {
+        const long off = ((long)aa * ntaps + t0 + t) * B + b0 + b;
+        for (int s = 0; s < nsplit; ++s) v += part[s * total + off];
+      }
+      tile[t][b] = v;
+    }
+    __syncthreads();
+    const int nb = B - b0 < 64 ? B - b0 : 64;
+    for (int i = threadIdx.x; i < nb * nt; i += blockDim.x) {
+      const int b = i / nt, t = i % nt;
+      const long o = ((long)aa * B + b0 + b) * ntaps + t0 + t;
+      dw[o] = accumulate ? dw[o] + tile[t][b] : tile[t][b];
+    }
+    __syncthreads();
   }
+}
+
+// ---- thin layers (A <= 16 and B <= 16 channels: the 1/12-channel U-Net levels and the 1x1x1 heads) -------------
+// One tap per workgroup would re-stream both operands 27 times for one MFMA each; here a workgroup owns a slice of the
+// rows for ALL taps (up to TMAX per group): per 32-row step the G tile is staged once, every tap's shifted X tile
+// next to it, and the four waves take the taps round-robin (2+2 transposing LDS reads and one MFMA per tap).
+#define WT_TMAX 28
+struct ThinRow { long goff; long xoff; int id, ih, iw, ok; };
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[(WT_TMAX + 1) * 32 * 16];
+  __shared__ ThinRow ri[32];
+  __shared__ int4 tapinfo[WT_TMAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntaps = a.TD * a.TH * a.TW;
+  const int t0 = blockIdx.x * WT_TMAX;
+  const int nt = ntaps - t0 < WT_TMAX ? ntaps - t0 : WT_TMAX;
+  if (tid < nt) {
+    const int tap = t0 + tid;
+    const int kw = tap % a.TW, kh = (tap / a.TW) % a.TH, kd = tap / (a.TW * a.TH);
+    const int dd = kd * a.ts[0], dh = kh * a.ts[1], dw = kw * a.ts[2];
+    tapinfo[tid] = make_int4(dd, dh, dw, (int)(dd * a.xsd + dh * a.xsh + dw * a.xsw));
+  }
+  const long mbeg = (long)blockIdx.z * a.rows_per_split;
+  long mend = mbeg + a.rows_per_split; if (mend > a.M) mend = a.M;
+  const int nsteps = (int)((mend - mbeg + 31) / 32);
+  f32x4 acc[(WT_TMAX + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (WT_TMAX + 3) / 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b64;
+  for (int s = 0; s < nsteps; ++s) {
+    __syncthreads();  // previous step's fragment reads are done
+    if (tid < 32) {
+      const long m = mbeg + (long)s * 32 + tid;
+      ThinRow r; r.ok = m < mend; r.goff = 0; r.xoff = 0; r.id = r.ih = r.iw = 0;
+      if (r.ok) {
+        long t = m;
+        const int rw = (int)(t % a.RW); t /= a.RW;
+        const int rh = (int)(t % a.RH); t /= a.RH;
+        const int rd = (int)(t % a.RD); t /= a.RD;
+        r.goff = t * a.gsn + rd * a.gsd + rh * a.gsh + rw * a.gsw;
+        r.id = rd * a.rs[0] + a.tb[0]; r.ih = rh * a.rs[1] + a.tb[1]; r.iw = rw * a.rs[2] + a.tb[2];
+        r.xoff = t * a.xsn + r.id * a.xsd + r.ih * a.xsh + r.iw * a.xsw;
+      }
+      ri[tid] = r;
+    }
+    __syncthreads();
+    {
+      // thread -> fixed (row, 8-lane half); it walks the tiles 4 apart: tile 0 = G, tile 1+t = X at tap t0+t
+      const int row = (tid >> 1) & 31, c = (tid & 1) * 8;
+      const ThinRow r = ri[row];
+      const bool cb = c < a.blanes;
+      constexpr int NL = (WT_TMAX + 1 + 3) / 4;
+      bf16x8 v[NL];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {  // issue every load before the first LDS store (one exposed latency, not NL)
+        const int tile = (tid >> 6) + 4 * k;
+        v[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (r.ok && tile <= nt) {
+          if (tile == 0) { if (c < a.alanes) v[k] = *(const bf16x8*)(a.g + r.goff + c); }
+          else {
+            const int4 ti = tapinfo[tile - 1];  // (dd, dh, dw, element offset)
+            const int id = r.id + ti.x, ih = r.ih + ti.y, iw = r.iw + ti.z;
+            if (cb && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+              v[k] = *(const bf16x8*)(a.x + r.xoff + ti.w + c);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const int tile = (tid >> 6) + 4 * k;
+        if (tile <= nt) *(bf16x8*)(lds + (tile * 32 + row) * 16 + c) = v[k];
+      }
+    }
+    __syncthreads();
+    const bf16_t* gb = lds + (8 * fg + fq) * 16 + 4 * fp;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb + 4 * 16));
+    const bf16x8 gf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int i = 0; i < (WT_TMAX + 3) / 4; ++i) {
+      const int t = wave + 4 * i;
+      if (t < nt) {
+        const bf16_t* xb = lds + ((1 + t) * 32 + 8 * fg + fq) * 16 + 4 * fp;
+        bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
+        bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
+        const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
+  const int bb = lane & 15;
+#pragma unroll
+  for (int i = 0; i < (WT_TMAX + 3) / 4; ++i) {
+    const int t = wave + 4 * i;
+    if (t >= nt) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int aa = fg * 4 + r;
+      if (aa < a.A && bb < a.B) out[((long)aa * ntaps + t0 + t) * a.B + bb] = acc[i][r];
+    }
+  }
+}
+
+// ---- thin layers, line-aligned variant (row stride 1, tap step +1: every stride-1 convolution) ------------------
+// K-steps are 32 consecutive voxels of ONE output line, so the three (TW) kw-taps of a (kd,kh) pair read the same
+// staged input line segment at row offsets 0..TW-1: 1 + TD*TH tiles are loaded per step instead of 1 + TD*TH*TW
+// (10.8 KB instead of 28.7 KB for 3x3x3), and ds_read_b64_tr_b16 still sees 4 consecutive k-rows per block.
+#define WL_MAXJ 9    /* (kd,kh) pairs per workgroup */
+#define WL_MAXW 8    /* taps along W */
+struct WgradLineArgs { WgradArgs w; long units; long units_per_split; int wchunks; };
+__global__ __launch_bounds__(256) void wgrad_line_kernel(WgradLineArgs p) {
+  const WgradArgs& a = p.w;
+  constexpr int XR = 32 + WL_MAXW - 1;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[(32 + WL_MAXJ * XR) * 16];
+  bf16_t* Gs = lds;
+  bf16_t* Xs = lds + 32 * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntaps = a.TD * a.TH * a.TW;
+  const int TDH = a.TD * a.TH;
+  const int j0 = blockIdx.x * WL_MAXJ;
+  const int nj = TDH - j0 < WL_MAXJ ? TDH - j0 : WL_MAXJ;
+  const int xrows = 32 + a.TW - 1;
+  const long ubeg = (long)blockIdx.z * p.units_per_split;
+  long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
+  constexpr int NACC = (WL_MAXJ * WL_MAXW + 3) / 4;
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b64;
+  const int nloc = nj * a.TW;  // taps of this workgroup: local index t = jj*TW + kw
+  // per-thread load list, fixed for the whole kernel: code = jj<<10 | row<<4 | half*8 (jj == 15: the G tile), -1 = none
+  constexpr int NLD = (64 + WL_MAXJ * XR * 2 + 255) / 256;
+  int lc[NLD], lkh[NLD], lkd[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int q = tid + 256 * k;
+    lc[k] = -1; lkh[k] = lkd[k] = 0;
+    if (q < 64) lc[k] = (15 << 10) | ((q >> 1) << 4) | ((q & 1) * 8);
+    else if (q < 64 + nj * xrows * 2) {
+      const int q2 = q - 64, rr = (q2 >> 1) % xrows, jj = (q2 >> 1) / xrows;
+      lc[k] = (jj << 10) | (rr << 4) | ((q2 & 1) * 8);
+      lkh[k] = (j0 + jj) % a.TH; lkd[k] = (j0 + jj) / a.TH;
+    }
+  }
+  for (long u = ubeg; u < uend; ++u) {
+    unsigned t = (unsigned)u;  // units < 2^31 (host-checked): 32-bit divisions only
+    const int wc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd = (int)(t % (unsigned)a.RD); const long n = t / (unsigned)a.RD;
+    const int w0 = wc * 32;
+    __syncthreads();  // previous step's fragment reads are done
+    // G tile: 32 rows x 2 halves; X tiles: nj x xrows x 2 halves
+    const long gline = n * a.gsn + rd * a.gsd + rh * a.gsh;
+    const long xline = n * a.xsn;
+    bf16x8 v[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {  // all loads first, then all LDS stores
+      v[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      const int cc = lc[k] & 8, rr = (lc[k] >> 4) & 63, jj = lc[k] >> 10;
+      if (lc[k] < 0) continue;
+      if (jj == 15) {
+        if (w0 + rr < a.RW && cc < a.alanes) v[k] = *(const bf16x8*)(a.g + gline + (long)(w0 + rr) * a.gsw + cc);
+      } else {
+        const int j = j0 + jj, kh = lkh[k], kd = lkd[k];
+        (void)j;
+        const int id = rd + a.tb[0] + kd, ih = rh + a.tb[1] + kh, iw = w0 + a.tb[2] + rr;
+        if (cc < a.blanes && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+          v[k] = *(const bf16x8*)(a.x + xline + (long)id * a.xsd + (long)ih * a.xsh + (long)iw * a.xsw + cc);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      if (lc[k] < 0) continue;
+      const int cc = lc[k] & 8, rr = (lc[k] >> 4) & 63, jj = lc[k] >> 10;
+      if (jj == 15) *(bf16x8*)(Gs + rr * 16 + cc) = v[k];
+      else *(bf16x8*)(Xs + (jj * XR + rr) * 16 + cc) = v[k];
+    }
+    __syncthreads();
+    const bf16_t* gb = Gs + (8 * fg + fq) * 16 + 4 * fp;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb + 4 * 16));
+    const bf16x8 gf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int tl = wave + 4 * i;
+      if (tl < nloc) {
+        const int jj = tl / a.TW, kw = tl % a.TW;
+        const bf16_t* xb = Xs + (jj * XR + kw + 8 * fg + fq) * 16 + 4 * fp;
+        bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
+        bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
+        const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
+  const int bb = lane & 15;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int tl = wave + 4 * i;
+    if (tl >= nloc) continue;
+    const int tap = (j0 + tl / a.TW) * a.TW + tl % a.TW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int aa = fg * 4 + r;
+      if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[i][r];
+    }
+  }
+}
+static bool wgrad_line_ok(const rg_conv_params* p, int fa, int fb) {
+  if (fa != 1 || fb != 1) return false;
+  for (int d = 0; d < 3; ++d) if (p->rstride[d] != 1 || p->tstep[d] != 1) return false;
+  return p->T[2] <= WL_MAXW;
 }
 
 static int pick_f(int lanes) {
@@ -188,13 +436,24 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   *fa = pick_f(G.lanes); *fb = pick_f(X.lanes);
   const long M = (long)G.N * p->R[0] * p->R[1] * p->R[2];
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
-  const long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
+  long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
+  if (*fa == 1 && *fb == 1) tiles = (ntaps + WT_TMAX - 1) / WT_TMAX;  // wgrad_thin_kernel: all taps in one workgroup
+  if (wgrad_line_ok(p, *fa, *fb)) {  // wgrad_line_kernel: split over (line, 32-voxel chunk) units
+    const long wch = (p->R[2] + 31) / 32;
+    const long units = (long)G.N * p->R[0] * p->R[1] * wch;
+    const long groups = (p->T[0] * p->T[1] + WL_MAXJ - 1) / WL_MAXJ;
+    long ns = 2048 / groups; if (ns > units / 8) ns = units / 8; if (ns < 1) ns = 1;
+    const long ups = (units + ns - 1) / ns;
+    *nsplit = (int)((units + ups - 1) / ups);
+    *rows_per_split = ups;  // units per split
+    return;
+  }
   long want = (2048 + tiles - 1) / tiles;           // aim at >= 2048 workgroups
-  long maxs = (M + 32 * 16 - 1) / (32 * 16);         // at least 16 K-steps per split
+  long maxs = (M + 64 * 8 - 1) / (64 * 8);           // at least 8 K-steps per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
-  long rps = ((M + want - 1) / want + 31) / 32 * 32;
+  long rps = ((M + want - 1) / want + 63) / 64 * 64;
   *nsplit = (int)((M + rps - 1) / rps);
   *rows_per_split = rps;
 }
@@ -214,7 +473,8 @@ extern "C" int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_
   int fa, fb, ns; long rps;
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   if (nsplit_out) *nsplit_out = ns;
-  return (int64_t)ns * G.C * X.C * p->T[0] * p->T[1] * p->T[2] * 4;
+  const int64_t total = (int64_t)G.C * X.C * p->T[0] * p->T[1] * p->T[2];
+  return (ns + (ns > 64 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;
 }
 
 template <int FA, int FB, int WA, int WB>
@@ -242,7 +502,9 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   int fa, fb, ns; long rps;
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
-  const size_t need = (size_t)ns * G.C * X.C * ntaps * 4;
+  const size_t total_el = (size_t)G.C * X.C * ntaps;
+  const int nfold = ns > 64 ? (ns + WF_FOLD - 1) / WF_FOLD : 0;
+  const size_t need = (size_t)(ns + nfold) * total_el * 4;
   if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   if (!dw) RG_FAIL(RG_ERR_BAD_SHAPE, "wgrad: null dw");
   WgradArgs a;
@@ -256,17 +518,34 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   a.A = G.C; a.B = X.C; a.alanes = G.lanes; a.blanes = X.lanes;
   a.M = (long)G.N * a.RD * a.RH * a.RW; a.rows_per_split = rps; a.nsplit = ns;
   hipStream_t st = (hipStream_t)s;
+  if (wgrad_line_ok(p, fa, fb)) {
+    WgradLineArgs la; la.w = a;
+    la.wchunks = (a.RW + 31) / 32;
+    la.units = (long)G.N * a.RD * a.RH * la.wchunks;
+    la.units_per_split = rps;
+    rg_set_kernel_name("wgrad_line_kernel");
+    hipLaunchKernelGGL(wgrad_line_kernel, dim3((a.TD * a.TH + WL_MAXJ - 1) / WL_MAXJ, 1, ns), dim3(256), 0, st, la);
+  } else if (fa == 1 && fb == 1) {
+    rg_set_kernel_name("wgrad_thin_kernel");
+    hipLaunchKernelGGL(wgrad_thin_kernel, dim3((ntaps + WT_TMAX - 1) / WT_TMAX, 1, ns), dim3(256), 0, st, a);
+  } else
   switch (fa) {
     case 1: WG_ROW(1, 1); break;
     case 4: WG_ROW(4, 2); break;
     case 5: WG_ROW(5, 1); break;
     case 8: WG_ROW(8, 2); break;
-    default: WG_ROW(9, 3); break;
+    default: WG_ROW(9, 1); break;  // 144x144 tile as 1x3 waves of 144x48: 12 fragment reads per 27 MFMAs
   }
   RG_CHECK_LAUNCH();
-  const long total = (long)G.C * X.C * ntaps;
-  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, G.C, X.C, ntaps, ns, accumulate);
+  const float* fin = (const float*)workspace;
+  int nfin = ns;
+  if (nfold) {
+    float* folded = (float*)workspace + (size_t)ns * total_el;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total_el + 255) / 256), nfold), dim3(256), 0, st, (const float*)workspace, folded, (long)total_el, ns);
+    RG_CHECK_LAUNCH();
+    fin = folded; nfin = nfold;
+  }
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(G.C * ((X.C + 63) / 64)), dim3(256), 0, st, fin, dw, G.C, X.C, ntaps, nfin, accumulate);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
