@@ -1,0 +1,108 @@
+"""Block-wise volume prediction — the hot part of raygun.predict / raygun.torch.predict.worker without daisy/zarr
+(reference: src/raygun/predict.py:73-108 ROI arithmetic, :154-164 block task; src/raygun/torch/predict/worker.py:94-160
+per-block normalise -> forward -> crop -> convert -> write).
+
+  * read ROI = input_shape, write ROI = output_shape centred in it (context = (read - write)//2, predict.py:92-96), or
+    read_size / crop (predict.py:98-108); blocks tile the volume on the write-ROI grid;
+  * blocks whose read ROI does not fit inside the source are skipped (daisy `fit="valid"` default; enumeration order is
+    PARITY UNPINNED — results are order independent because write ROIs are disjoint, predict.py:159);
+  * the daisy scheduler and its worker processes are replaced by a static partition of the block list over ranks
+    (parallel.shard_blocks): no collective, every rank writes only its own blocks;
+  * per block: uint8/uint16 source -> (x - iinfo.min)/iinfo.max [* scale + shift] is fused into the layout-conversion
+    kernel (rg_copy_convert), the forward runs under no_grad in bf16, outputs are cropped, then either kept as float32 or
+    scaled by iinfo(dtype).max and clamped for integer destinations (worker.py:133-149).
+"""
+import numpy as np
+import torch
+
+from . import ops, parallel
+
+
+def roi_geometry(ndims=3, input_shape=None, output_shape=None, read_size=None, crop=0, voxel_size=(1, 1, 1)):
+    """-> (read_shape, write_shape, context) in voxels (predict.py:73-108; voxel_size cancels for isotropic voxels)."""
+    if input_shape is not None:
+        if not isinstance(input_shape, (list, tuple)):
+            input_shape = (1,) * (3 - ndims) + (input_shape,) * ndims
+            output_shape = (1,) * (3 - ndims) + (output_shape,) * ndims
+        read = tuple(int(v) for v in input_shape)
+        write = tuple(int(v) for v in output_shape)
+        context = tuple((r - w) // 2 for r, w in zip(read, write))
+    else:
+        read = (1,) * (3 - ndims) + (int(read_size),) * ndims
+        c = (0,) * (3 - ndims) + (int(crop),) * ndims
+        write = tuple(r - 2 * k for r, k in zip(read, c))
+        context = c
+    if any(w <= 0 for w in write):
+        raise ValueError(f"write ROI {write} is empty for read ROI {read}")
+    return read, write, context
+
+
+def enumerate_blocks(volume_shape, read, write, context):
+    """Write-ROI origins (z, y, x) of every block whose read ROI lies inside the volume, raster order."""
+    axes = []
+    for n, r, w in zip(volume_shape, read, write):
+        axes.append([o for o in range(0, n, w) if o + r <= n])
+    return [(z + context[0], y + context[1], x + context[2]) for z in axes[0] for y in axes[1] for x in axes[2]]
+
+
+def _to_destination(out, dtype):
+    """worker.py:133-149: integer destinations get *iinfo.max + clamp, float ones pass through."""
+    if np.issubdtype(np.dtype(dtype), np.integer):
+        info = np.iinfo(dtype)
+        out = torch.clamp(out * float(info.max), float(info.min), float(info.max))
+    return out.cpu().numpy().astype(dtype)
+
+
+@torch.no_grad()
+def predict_volume(model, source, input_shape=None, output_shape=None, read_size=None, crop=0, ndims=3,
+                   scaleShift_input=None, out_dtypes=None, out_channels=None, rank=None, world=None, device=None,
+                   destinations=None):
+    """Predict a (Z,Y,X) integer volume block by block.
+
+    model: callable taking a (1,1,z,y,x) tensor and returning a tensor or tuple of tensors (worker.py:116-119).
+    Returns (list of destination ndarrays, number of blocks this rank processed).  Destinations are zero where no block
+    wrote (borders; other ranks' blocks when world > 1)."""
+    source = np.asarray(source)
+    if source.ndim != 3:
+        raise ValueError("source must be a (Z, Y, X) volume")
+    if not np.issubdtype(source.dtype, np.integer):
+        raise TypeError("source must be an integer volume (worker.py:109-110 normalises with np.iinfo)")
+    dev = torch.device(device if device is not None else "cuda")
+    read, write, context = roi_geometry(ndims, input_shape, output_shape, read_size, crop)
+    blocks = enumerate_blocks(source.shape, read, write, context)
+    mine = parallel.shard_blocks(len(blocks), rank, world)
+    info = np.iinfo(source.dtype)
+    scale, shift = 1.0 / float(info.max), -float(info.min) / float(info.max)
+    if scaleShift_input is not None:  # worker.py:112-114
+        scale, shift = scale * scaleShift_input[0], shift * scaleShift_input[0] + scaleShift_input[1]
+    if hasattr(model, "eval"):
+        model.eval()
+    src_t = torch.from_numpy(np.ascontiguousarray(source))
+    n_done = 0
+    for bi in mine:
+        wz, wy, wx = blocks[bi]
+        rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
+        blk = src_t[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]].to(dev, non_blocking=True)[None, None]
+        if blk.dtype not in (torch.uint8,):
+            blk = blk.float()
+        x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
+        outs = model(x)
+        if not isinstance(outs, (tuple, list)):
+            outs = (outs,)
+        if destinations is None:
+            destinations = []
+            for i, o in enumerate(outs):
+                c = o.shape[1]
+                dt = np.float32 if out_dtypes is None else out_dtypes[i]
+                destinations.append(np.zeros(((c,) if c > 1 else ()) + tuple(source.shape), dtype=dt))
+        for o, dest in zip(outs, destinations):
+            o = o.detach().float()[0]
+            if crop and crop != 0 and input_shape is None:
+                o = o[..., crop:-crop, crop:-crop, crop:-crop]
+            if tuple(o.shape[-3:]) != tuple(write):
+                off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
+                o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
+            arr = _to_destination(o if dest.ndim == 4 else o[0], dest.dtype)
+            dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = arr
+        n_done += 1
+    return destinations, n_done

@@ -1,0 +1,59 @@
+"""Block runner: ROI arithmetic (CPU) and block-wise == whole-volume prediction on the GPU (valid U-Net: translation
+equivariant on the write grid, so tiling must reproduce the single-pass result wherever blocks write)."""
+import numpy as np
+import pytest
+import torch
+
+from raygun_amd import predict as P, synth
+
+
+def test_roi_geometry_matches_reference_arithmetic():
+    # predict.py:92-96 with the MTLSD shapes (default_MTLSD_conf.json:132-141): 196 -> 104, context 46
+    read, write, ctx = P.roi_geometry(3, [196, 196, 196], [104, 104, 104])
+    assert (read, write, ctx) == ((196,) * 3, (104,) * 3, (46,) * 3)
+    # scalar shapes are broadcast over ndims with leading singleton dims for 2-D (predict.py:81-87)
+    read, write, ctx = P.roi_geometry(2, 512, 472)
+    assert (read, write, ctx) == ((1, 512, 512), (1, 472, 472), (0, 20, 20))
+    # read_size / crop form (predict.py:98-108)
+    assert P.roi_geometry(3, read_size=64, crop=8) == ((64,) * 3, (48,) * 3, (8,) * 3)
+    with pytest.raises(ValueError):
+        P.roi_geometry(3, read_size=16, crop=8)
+
+
+def test_block_enumeration_and_sharding():
+    read, write, ctx = P.roi_geometry(3, [196] * 3, [104] * 3)
+    blocks = P.enumerate_blocks((2048,) * 3, read, write, ctx)
+    assert len(blocks) == 18 ** 3 == 5832
+    assert blocks[0] == (46, 46, 46) and blocks[-1] == (46 + 17 * 104,) * 3
+    from raygun_amd.parallel import shard_blocks
+    got = sorted(i for r in range(8) for i in shard_blocks(len(blocks), r, 8))
+    assert got == list(range(5832))
+    assert P.enumerate_blocks((100, 100, 100), read, write, ctx) == []  # volume smaller than one read ROI
+
+
+@pytest.mark.gpu
+def test_blockwise_equals_whole_volume():
+    from raygun_amd.torch.networks import UNet
+    dev = torch.device("cuda")
+    kw = dict(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True)
+    net = UNet(**kw)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict(), 3))
+    net = net.to(dev)
+    vol = (synth.uniform((60, 60, 60), 4, 0, 1) * 255).astype(np.uint8)
+    # this U-Net maps n -> n - 16 (n even); read 36 -> write 20
+    dests, n = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1])
+    assert n == 8 and dests[0].shape == (4, 60, 60, 60) and dests[0].dtype == np.float32
+    with torch.no_grad():
+        x = torch.from_numpy(vol.astype(np.float32) / 255 * 2 - 1)[None, None].to(dev)
+        whole = net(x)[0].cpu().numpy()  # (4, 44, 44, 44), origin at voxel 8
+    tiled = dests[0][:, 8:48, 8:48, 8:48]
+    ref = whole[:, 0:40, 0:40, 0:40]
+    assert np.abs(tiled - ref).max() <= 2e-2 * np.abs(ref).max()
+    assert (dests[0][:, :8] == 0).all()
+    # integer destination: *iinfo.max + clamp (worker.py:133-144)
+    d8, _ = P.predict_volume(lambda t: torch.sigmoid(net(t)), vol, input_shape=[36] * 3, output_shape=[20] * 3, out_dtypes=[np.uint8])
+    assert d8[0].dtype == np.uint8 and d8[0].max() > 0
+    # two ranks: disjoint halves that add up to the single-rank result
+    a, na = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1], rank=0, world=2)
+    b, nb_ = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1], rank=1, world=2)
+    assert na + nb_ == 8 and np.array_equal(a[0] + b[0], dests[0])
