@@ -349,8 +349,28 @@ class _Conv3d(torch.autograd.Function):
         return gx, dw, db, None, None, None, None
 
 
+def _fold_w(x, kw, stride_w, pad):
+    """Single-channel input: fold the KW taps along W into channels.  out[n, c, d, h, w'] = xpad[n, 0, d, h, w'*s + c],
+    an overlapping strided view of the (zero-padded) channels-last buffer, materialised once as a 8-lane tensor.  A
+    1 -> Cout conv with KD*KH*KW taps of ONE channel (31/32 of every 32-deep MFMA step zero) becomes a KW -> Cout conv with
+    KD*KH taps: 343 K-steps -> 49 for the generator's 7^3 stem (networks/ResNet.py:283)."""
+    x = enter(x)
+    if any(pad):
+        x = pad3d(x, pad, "zeros")
+    n, _, d, h, w = x.shape
+    wo = (w - kw) // stride_w + 1
+    sn, _, sd, sh, sw = x.stride()
+    view = torch.as_strided(x, (n, kw, d, h, wo), (sn, sw, sd, sh, sw * stride_w), x.storage_offset())
+    return _ToCL.apply(view)
+
+
 def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
-    return _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), act, float(slope))
+    stride, padding = _triple(stride), _triple(padding)
+    if weight.shape[1] == 1 and 1 < weight.shape[4] <= 8 and x.shape[1] == 1 and x.is_cuda:
+        xf = _fold_w(x, weight.shape[4], stride[2], padding)
+        wf = weight.permute(0, 4, 2, 3, 1)  # (Cout, KW, KD, KH, 1): autograd maps the gradient back
+        return _Conv3d.apply(xf, wf, bias, (stride[0], stride[1], 1), (0, 0, 0), act, float(slope))
+    return _Conv3d.apply(x, weight, bias, stride, padding, act, float(slope))
 
 
 class _ConvTranspose3d(torch.autograd.Function):
