@@ -421,6 +421,181 @@ static bool wgrad_line_ok(const rg_conv_params* p, int fa, int fb) {
   return p->T[2] <= WL_MAXW;
 }
 
+// ---- wide layers, line-aligned K-steps with kw reuse --------------------------------------------------------------
+// The flat kernel above is bound by the global->LDS path (measured ~25-30 GB/s per CU): a 144x144 tile moves 18.4 KB per
+// 32-row step for ONE tap (72 FLOP/B).  Here a K-step is 32 consecutive voxels of one output line and the workgroup owns
+// ALL TW taps of one (kd,kh): the X line segment (32+TW-1 rows) is staged once and read at row offsets 0..TW-1 by the
+// transposing LDS reads, the G tile once for TW taps: ~TW times the FLOP per byte (216 FLOP/B for 3x3x3 at 144x144,
+// 206 for the 7^3 64x64 layer).  Cost: lines are padded to multiples of 32 rows (host picks this kernel when that
+// wastes less than half the MFMA work).  Wave (wa, wb) owns an IAxIB block of 16x16 fragments for every kw.
+struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; };
+
+template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP>
+__global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
+  const WgradArgs& a = p.w;
+  constexpr int NT = WA * WB * WT * 64;
+  constexpr int TPW = (TWM + WT - 1) / WT;  // taps per wave: wave wt owns taps wt, wt+WT, ...
+  constexpr int TA = FA * 16, TB = FB * 16;
+  constexpr int SA = wg_pad(TA), SB = wg_pad(TB);
+  constexpr int CA = TA / 8, CB = TB / 8;
+  constexpr int XR = 32 + TWM - 1;
+  constexpr int NCH = 32 * CA + XR * CB;
+  constexpr int PER_T = (NCH + NT - 1) / NT;
+  constexpr int IA = FA / WA, IB = FB / WB;
+  static_assert(FA % WA == 0 && FB % WB == 0, "wave layout must divide the tile");
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (32 * SA + XR * SB)];
+  bf16_t* Gs = lds;                   // [2][32][SA]
+  bf16_t* Xs = lds + 2 * 32 * SA;     // [2][XR][SB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wt = wave / (WA * WB), wa = (wave / WB) % WA, wb = wave % WB;
+  const int a0 = (blockIdx.x / p.ntb) * TA, b0 = (blockIdx.x % p.ntb) * TB;
+  const int kh = blockIdx.y % a.TH, kd = blockIdx.y / a.TH;
+  const int xrows = 32 + a.TW - 1;
+  const long ubeg = (long)blockIdx.z * p.units_per_split;
+  long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
+
+  // fixed per-thread chunk list: code = isX<<16 | row<<8 | chunk ; -1 = none
+  int lc[PER_T];
+#pragma unroll
+  for (int k = 0; k < PER_T; ++k) {
+    const int q = tid + NT * k;
+    lc[k] = -1;
+    if (q < 32 * CA) lc[k] = ((q / CA) << 8) | (q % CA);
+    else if (q < 32 * CA + xrows * CB) { const int q2 = q - 32 * CA; lc[k] = (1 << 16) | ((q2 / CB) << 8) | (q2 % CB); }
+  }
+  f32x4 acc[TPW][IA][IB];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+      for (int j = 0; j < IB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 regs0[PER_T], regs1[DEEP ? PER_T : 1];  // DEEP: two K-steps in flight through the registers
+  auto gload = [&](bf16x8 (&regs)[PER_T], long u) {
+    unsigned t = (unsigned)u;
+    const int wc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd = (int)(t % (unsigned)a.RD); const long n = t / (unsigned)a.RD;
+    const int w0 = wc * 32;
+    const long gline = n * a.gsn + rd * a.gsd + rh * a.gsh;
+    const int id = rd * a.rs[0] + a.tb[0] + kd * a.ts[0], ih = rh * a.rs[1] + a.tb[1] + kh * a.ts[1];
+    const bool line_ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
+    const long xline = n * a.xsn + (long)id * a.xsd + (long)ih * a.xsh;
+    const int iw0 = w0 + a.tb[2];
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+      bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      const int code = lc[k];
+      if (code >= 0) {
+        const int row = (code >> 8) & 255, ch = code & 255;
+        if (code >> 16) {
+          const int c = b0 + ch * 8, iw = iw0 + row;
+          if (line_ok && c < a.blanes && (unsigned)iw < (unsigned)a.IW) v = *(const bf16x8*)(a.x + xline + (long)iw * a.xsw + c);
+        } else {
+          const int c = a0 + ch * 8;
+          if (w0 + row < a.RW && c < a.alanes) v = *(const bf16x8*)(a.g + gline + (long)(w0 + row) * a.gsw + c);
+        }
+      }
+      regs[k] = v;
+    }
+  };
+  auto lstore = [&](bf16x8 (&regs)[PER_T], int buf) {
+#pragma unroll
+    for (int k = 0; k < PER_T; ++k) {
+      const int code = lc[k];
+      if (code < 0) continue;
+      const int row = (code >> 8) & 255, ch = code & 255;
+      if (code >> 16) *(bf16x8*)(Xs + (buf * XR + row) * SB + ch * 8) = regs[k];
+      else *(bf16x8*)(Gs + (buf * 32 + row) * SA + ch * 8) = regs[k];
+    }
+  };
+
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b64;
+  auto compute = [&](int buf) {
+    bf16x8 gf[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const bf16_t* base = Gs + (buf * 32 + 8 * fg + fq) * SA + (wa * IA + i) * 16 + 4 * fp;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SA));
+      gf[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+      const int t = wt + tt * WT;
+      if (t < a.TW) {
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+          const bf16_t* base = Xs + (buf * XR + t + 8 * fg + fq) * SB + (wb * IB + j) * 16 + 4 * fp;
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SB));
+          const bf16x8 xf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int i = 0; i < IA; ++i) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[tt][i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if constexpr (DEEP) {
+    // step u's operands sit in registers two steps ahead; LDS is double-buffered, one barrier per step
+    if (ubeg < uend) gload(regs0, ubeg);
+    if (ubeg + 1 < uend) gload(regs1, ubeg + 1);
+    for (long u = ubeg; u < uend; u += 2) {
+      lstore(regs0, 0);
+      __syncthreads();
+      if (u + 2 < uend) gload(regs0, u + 2);
+      compute(0);
+      if (u + 1 < uend) {
+        lstore(regs1, 1);
+        __syncthreads();
+        if (u + 3 < uend) gload(regs1, u + 3);
+        compute(1);
+      }
+    }
+  } else {
+    if (ubeg < uend) gload(regs0, ubeg);
+    int buf = 0;
+    for (long u = ubeg; u < uend; ++u, buf ^= 1) {
+      lstore(regs0, buf);
+      __syncthreads();
+      if (u + 1 < uend) gload(regs0, u + 1);
+      compute(buf);
+    }
+  }
+
+  const int ntaps = a.TD * a.TH * a.TW;
+  float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int t = wt + tt * WT;
+    if (t >= a.TW) continue;
+    const int tap = (kd * a.TH + kh) * a.TW + t;
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+      for (int j = 0; j < IB; ++j) {
+        const int bb = b0 + (wb * IB + j) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int aa = a0 + (wa * IA + i) * 16 + fg * 4 + r;
+          if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[tt][i][j][r];
+        }
+      }
+  }
+}
+// which (FA, FB) tiles have a kw-reuse instantiation, and for how many W taps
+static int wgrad_kw_kind(const rg_conv_params* p, int fa, int fb) {
+  if (p->rstride[2] != 1 || p->tstep[2] != 1 || p->T[2] < 2) return 0;
+  const int rw = p->R[2];
+  if (rw * 2 < round_up(rw, 32)) return 0;  // lines padded to 32 rows would waste more than half the MFMA work
+  if (fa == 9 && fb == 9 && p->T[2] <= 3) return 1;
+  if (fa == 4 && fb == 4 && p->T[2] <= 8) return 2;
+  if (fa == 8 && fb == 8 && p->T[2] <= 4) return 3;
+  return 0;
+}
+
 static int pick_f(int lanes) {
   // channel-tile menu (fragments of 16): 1, 4, 5, 8, 9
   if (lanes <= 16) return 1;
@@ -438,6 +613,17 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
   if (*fa == 1 && *fb == 1) tiles = (ntaps + WT_TMAX - 1) / WT_TMAX;  // wgrad_thin_kernel: all taps in one workgroup
+  if (wgrad_kw_kind(p, *fa, *fb)) {  // wgrad_kw_kernel: split over (line, 32-voxel chunk) units
+    const long wch = (p->R[2] + 31) / 32;
+    const long units = (long)G.N * p->R[0] * p->R[1] * wch;
+    const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
+    const long target = wgrad_kw_kind(p, *fa, *fb) == 3 ? 768 : 1536;  // workgroups aimed at (measured per tile shape)
+    long ns = (target + tl - 1) / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
+    const long ups = (units + ns - 1) / ns;
+    *nsplit = (int)((units + ups - 1) / ups);
+    *rows_per_split = ups;
+    return;
+  }
   if (wgrad_line_ok(p, *fa, *fb)) {  // wgrad_line_kernel: split over (line, 32-voxel chunk) units
     const long wch = (p->R[2] + 31) / 32;
     const long units = (long)G.N * p->R[0] * p->R[1] * wch;
@@ -518,7 +704,18 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   a.A = G.C; a.B = X.C; a.alanes = G.lanes; a.blanes = X.lanes;
   a.M = (long)G.N * a.RD * a.RH * a.RW; a.rows_per_split = rps; a.nsplit = ns;
   hipStream_t st = (hipStream_t)s;
-  if (wgrad_line_ok(p, fa, fb)) {
+  if (const int kind = wgrad_kw_kind(p, fa, fb)) {
+    WgradKwArgs ka; ka.w = a;
+    ka.wchunks = (a.RW + 31) / 32;
+    ka.units = (long)G.N * a.RD * a.RH * ka.wchunks;
+    ka.units_per_split = rps;
+    ka.nta = (a.A + fa * 16 - 1) / (fa * 16); ka.ntb = (a.B + fb * 16 - 1) / (fb * 16);
+    dim3 grid(ka.nta * ka.ntb, a.TD * a.TH, ns);
+    rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
+    if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
+    else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
+    else hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
+  } else if (wgrad_line_ok(p, fa, fb)) {
     WgradLineArgs la; la.w = a;
     la.wchunks = (a.RW + 31) / 32;
     la.units = (long)G.N * a.RD * a.RH * la.wchunks;

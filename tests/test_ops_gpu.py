@@ -76,6 +76,12 @@ CONV_CASES = [
     (144, 432, 3, 1, 0, (6, 6, 7), "relu"),
     (64, 72, 7, 1, 0, (9, 9, 9), "none"),
     (128, 64, 4, 2, 1, (10, 10, 10), "leaky"),
+    # line-aligned kw-reuse weight-gradient kernel (stride-1 W, output lines >= 16 voxels): 144x144/3, 64x64/7, 128x128/4 taps
+    (144, 144, 3, 1, 0, (4, 5, 21), "relu"),
+    (144, 288, 3, 1, 1, (3, 4, 40), "none"),
+    (64, 64, 7, 1, 0, (8, 9, 26), "none"),
+    (128, 128, 4, 1, 1, (4, 5, 33), "leaky"),
+    (128, 128, 3, 1, 1, (3, 3, 18), "none"),
 ]
 
 
