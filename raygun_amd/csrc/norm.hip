@@ -79,14 +79,17 @@ __global__ void norm_reduce_kernel(CL5 x, CL5 y, CL5 gy, const float* mr, float*
     for (int k = 0; k < 8; ++k) { o[k * 2] = s0[k]; o[k * 2 + 1] = s1[k]; }
   }
 }
-// MODE 0: out = (mean, rstd).  MODE 1: out = (mean_g, mean_gxhat)
+// MODE 0: out = (mean, rstd).  MODE 1: out = (mean_g, mean_gxhat).  One 64-lane wave per (n,c): strided partial sums in
+// double, fixed-order shuffle tree (deterministic).
 template <int MODE>
 __global__ void norm_finalize_kernel(const float* partial, float* out, int N, int C, int lanes, int nblk, long nvox, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x;
   if (i >= N * C) return;
   const int n = i / C, c = i % C;
   double a = 0, b = 0;
-  for (int k = 0; k < nblk; ++k) { const float* p = partial + (((long)n * nblk + k) * lanes + c) * 2; a += p[0]; b += p[1]; }
+  for (int k = threadIdx.x; k < nblk; k += 64) { const float* p = partial + (((long)n * nblk + k) * lanes + c) * 2; a += p[0]; b += p[1]; }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if (threadIdx.x != 0) return;
   if (MODE == 0) {
     const double mean = a / nvox; double var = b / nvox - mean * mean; if (var < 0) var = 0;
     out[i * 2] = (float)mean; out[i * 2 + 1] = (float)(1.0 / sqrt(var + eps));
@@ -102,7 +105,7 @@ extern "C" int rg_instnorm_stats(const rg_tensor* x, float* mean_rstd, float eps
   dim3 grid(p.nblk, (X.lanes / 8 + p.gx - 1) / p.gx, X.N), block(p.gx, p.gy);
   hipLaunchKernelGGL((norm_reduce_kernel<0>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, X, X, (const float*)nullptr, (float*)workspace, p.vpb, 0, 0.f);
   RG_CHECK_LAUNCH();
-  hipLaunchKernelGGL((norm_finalize_kernel<0>), dim3((X.N * X.C + 63) / 64), dim3(64), 0, (hipStream_t)s, (const float*)workspace, mean_rstd, X.N, X.C, X.lanes, p.nblk,
+  hipLaunchKernelGGL((norm_finalize_kernel<0>), dim3(X.N * X.C), dim3(64), 0, (hipStream_t)s, (const float*)workspace, mean_rstd, X.N, X.C, X.lanes, p.nblk,
                      (long)X.D * X.H * X.W, eps);
   RG_CHECK_LAUNCH();
   return RG_OK;
@@ -188,7 +191,7 @@ extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const
   dim3 grid(p.nblk, (X.lanes / 8 + p.gx - 1) / p.gx, X.N), block(p.gx, p.gy);
   hipLaunchKernelGGL((norm_reduce_kernel<1>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, Y, GY, mean_rstd, (float*)workspace, p.vpb, act, slope);
   RG_CHECK_LAUNCH();
-  hipLaunchKernelGGL((norm_finalize_kernel<1>), dim3((X.N * X.C + 63) / 64), dim3(64), 0, (hipStream_t)s, (const float*)workspace, gm, X.N, X.C, X.lanes, p.nblk,
+  hipLaunchKernelGGL((norm_finalize_kernel<1>), dim3(X.N * X.C), dim3(64), 0, (hipStream_t)s, (const float*)workspace, gm, X.N, X.C, X.lanes, p.nblk,
                      (long)X.D * X.H * X.W, 0.f);
   RG_CHECK_LAUNCH();
   const long total = (long)GX.N * GX.D * GX.H * GX.W * (GX.lanes / 8);

@@ -72,22 +72,37 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
 }
 
 // ---------------------------------------------------------------------------- weight packing
-__global__ void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
+// Tiled through LDS: a workgroup takes 16 values of dim0 x 16 of dim1 x all selected taps, reads them with the torch
+// layout's contiguous (dim1, tap) runs and writes them with the packed layout's contiguous reduced-channel runs.
+#define PK_T 16
+#define PK_MAXTAPS 64
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
+  __shared__ float tile[PK_T][PK_T][PK_MAXTAPS + 1];
   const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2];
-  const long total = (long)rows16 * ntap * red32;
-  const long kvol = (long)p.K[0] * p.K[1] * p.K[2];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % red32); long t = i / red32;
-    const int tap = (int)(t % ntap); const int r = (int)(t / ntap);
-    float v = 0.f;
-    if (r < rows && k < red) {
+  const int kvol = p.K[0] * p.K[1] * p.K[2];
+  const int n1 = (p.dim1 + PK_T - 1) / PK_T;
+  const int d0b = (blockIdx.x / n1) * PK_T, d1b = (blockIdx.x % n1) * PK_T;
+  for (int t0 = 0; t0 < kvol; t0 += PK_MAXTAPS) {  // chunks of the SOURCE tap axis
+    const int nt = kvol - t0 < PK_MAXTAPS ? kvol - t0 : PK_MAXTAPS;
+    for (int i = threadIdx.x; i < PK_T * PK_T * nt; i += 256) {
+      const int t = i % nt, d1 = (i / nt) % PK_T, d0 = i / (nt * PK_T);
+      float v = 0.f;
+      if (d0b + d0 < p.dim0 && d1b + d1 < p.dim1) v = w[((long)(d0b + d0) * p.dim1 + d1b + d1) * kvol + t0 + t];
+      tile[d0][d1][t] = v;
+    }
+    __syncthreads();
+    // packed index: [row][tap][red]; rows/red are dim0/dim1 (swap 0) or dim1/dim0 (swap 1)
+    for (int i = threadIdx.x; i < PK_T * PK_T * ntap; i += 256) {
+      const int kk = i % PK_T, tap = (i / PK_T) % ntap, rr = i / (PK_T * ntap);
       const int jw = tap % p.ntap[2], jh = (tap / p.ntap[2]) % p.ntap[1], jd = tap / (p.ntap[2] * p.ntap[1]);
       const int kd = p.k0[0] + p.kstep[0] * jd, kh = p.k0[1] + p.kstep[1] * jh, kw = p.k0[2] + p.kstep[2] * jw;
-      const long kidx = ((long)kd * p.K[1] + kh) * p.K[2] + kw;
-      const long d0 = p.swap ? k : r, d1 = p.swap ? r : k;
-      v = w[(d0 * p.dim1 + d1) * kvol + kidx];
+      const int kidx = (kd * p.K[1] + kh) * p.K[2] + kw;
+      if (kidx < t0 || kidx >= t0 + nt) continue;
+      const int d0 = p.swap ? kk : rr, d1 = p.swap ? rr : kk;
+      const int row = (p.swap ? d1b : d0b) + rr, k = (p.swap ? d0b : d1b) + kk;
+      if (row < rows && k < red) out[((long)row * ntap + tap) * red32 + k] = f2bf(tile[d0][d1][kidx - t0]);
     }
-    out[i] = f2bf(v);
+    __syncthreads();
   }
 }
 static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : 32; }
@@ -110,7 +125,10 @@ extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_param
   if (!w || !packed || pack_dims(p, &rows, &red)) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: bad params");
   const int rows16 = round_up(rows, 16), red32 = round_up(red, pack_align(p));
   const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total, 256, 1 << 16)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
+  // pad rows/lanes of the packed buffer are zero; the tiled kernel writes the real entries
+  if (hipMemsetAsync(packed, 0, (size_t)total * 2, (hipStream_t)s) != hipSuccess) RG_FAIL(RG_ERR_HIP, "pack_weights: memset failed");
+  const int nblk = ((p->dim0 + PK_T - 1) / PK_T) * ((p->dim1 + PK_T - 1) / PK_T);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
