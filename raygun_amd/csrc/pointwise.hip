@@ -72,35 +72,37 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
 }
 
 // ---------------------------------------------------------------------------- weight packing
-// Tiled through LDS: a workgroup takes 16 values of dim0 x 16 of dim1 x all selected taps, reads them with the torch
-// layout's contiguous (dim1, tap) runs and writes them with the packed layout's contiguous reduced-channel runs.
-#define PK_T 16
-#define PK_MAXTAPS 64
+// Tiled through LDS so that BOTH sides move whole 128-byte runs: a workgroup takes T0 values of dim0 x T1 of dim1 x a chunk
+// of source taps.  swap 0 (reduced channel = dim1): 1 x 64 — one contiguous 64*kvol-float read, 64-channel packed rows.
+// swap 1 (reduced channel = dim0): 64 x 4 — 4*kvol-float reads per dim0 value, again 64-channel packed rows.
+#define PK_ELEMS 256
+#define PK_MAXTAPS 32
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
-  __shared__ float tile[PK_T][PK_T][PK_MAXTAPS + 1];
+  __shared__ float tile[PK_ELEMS][PK_MAXTAPS + 1];
+  const int T0 = p.swap ? 64 : 1, T1 = p.swap ? 4 : 64;
   const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2];
   const int kvol = p.K[0] * p.K[1] * p.K[2];
-  const int n1 = (p.dim1 + PK_T - 1) / PK_T;
-  const int d0b = (blockIdx.x / n1) * PK_T, d1b = (blockIdx.x % n1) * PK_T;
+  const int n1 = (p.dim1 + T1 - 1) / T1;
+  const int d0b = (blockIdx.x / n1) * T0, d1b = (blockIdx.x % n1) * T1;
   for (int t0 = 0; t0 < kvol; t0 += PK_MAXTAPS) {  // chunks of the SOURCE tap axis
     const int nt = kvol - t0 < PK_MAXTAPS ? kvol - t0 : PK_MAXTAPS;
-    for (int i = threadIdx.x; i < PK_T * PK_T * nt; i += 256) {
-      const int t = i % nt, d1 = (i / nt) % PK_T, d0 = i / (nt * PK_T);
+    for (int i = threadIdx.x; i < T0 * T1 * nt; i += 256) {
+      const int t = i % nt, e = i / nt, d1 = e % T1, d0 = e / T1;
       float v = 0.f;
       if (d0b + d0 < p.dim0 && d1b + d1 < p.dim1) v = w[((long)(d0b + d0) * p.dim1 + d1b + d1) * kvol + t0 + t];
-      tile[d0][d1][t] = v;
+      tile[e][t] = v;
     }
     __syncthreads();
-    // packed index: [row][tap][red]; rows/red are dim0/dim1 (swap 0) or dim1/dim0 (swap 1)
-    for (int i = threadIdx.x; i < PK_T * PK_T * ntap; i += 256) {
-      const int kk = i % PK_T, tap = (i / PK_T) % ntap, rr = i / (PK_T * ntap);
+    const int TR = p.swap ? T1 : T0, TK = p.swap ? T0 : T1;  // packed rows / reduced channels inside the tile
+    for (int i = threadIdx.x; i < TR * TK * ntap; i += 256) {
+      const int kk = i % TK, tap = (i / TK) % ntap, rr = i / (TK * ntap);
       const int jw = tap % p.ntap[2], jh = (tap / p.ntap[2]) % p.ntap[1], jd = tap / (p.ntap[2] * p.ntap[1]);
       const int kd = p.k0[0] + p.kstep[0] * jd, kh = p.k0[1] + p.kstep[1] * jh, kw = p.k0[2] + p.kstep[2] * jw;
       const int kidx = (kd * p.K[1] + kh) * p.K[2] + kw;
       if (kidx < t0 || kidx >= t0 + nt) continue;
       const int d0 = p.swap ? kk : rr, d1 = p.swap ? rr : kk;
       const int row = (p.swap ? d1b : d0b) + rr, k = (p.swap ? d0b : d1b) + kk;
-      if (row < rows && k < red) out[((long)row * ntap + tap) * red32 + k] = f2bf(tile[d0][d1][kidx - t0]);
+      if (row < rows && k < red) out[((long)row * ntap + tap) * red32 + k] = f2bf(tile[d0 * T1 + d1][kidx - t0]);
     }
     __syncthreads();
   }
@@ -127,7 +129,8 @@ extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_param
   const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
   // pad rows/lanes of the packed buffer are zero; the tiled kernel writes the real entries
   if (hipMemsetAsync(packed, 0, (size_t)total * 2, (hipStream_t)s) != hipSuccess) RG_FAIL(RG_ERR_HIP, "pack_weights: memset failed");
-  const int nblk = ((p->dim0 + PK_T - 1) / PK_T) * ((p->dim1 + PK_T - 1) / PK_T);
+  const int pt0 = p->swap ? 64 : 1, pt1 = p->swap ? 4 : 64;
+  const int nblk = ((p->dim0 + pt0 - 1) / pt0) * ((p->dim1 + pt1 - 1) / pt1);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
   RG_CHECK_LAUNCH();
   return RG_OK;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
 // dw[a][b][tap] (+)= sum_s part[s][a][tap][b].  One workgroup = one `a` x 64 consecutive `b`: the [tap][64] slab is read
 // with coalesced 256-byte rows, transposed through LDS and written as one contiguous run of 64*ntaps floats.
 // out[j][i] = sum_{s in [j*R, (j+1)*R)} part[s][i]: folds many row splits (thin layers use up to 2048) before the finish
-#define WF_FOLD 32
+#define WF_FOLD 16
 __global__ void wgrad_fold_kernel(const float* part, float* out, long total, int nsplit) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -593,6 +593,15 @@ static int wgrad_kw_kind(const rg_conv_params* p, int fa, int fb) {
   if (fa == 9 && fb == 9 && p->T[2] <= 3) return 1;
   if (fa == 4 && fb == 4 && p->T[2] <= 8) return 2;
   if (fa == 8 && fb == 8 && p->T[2] <= 4) return 3;
+  if (p->T[2] == 3) {  // the 72/84/504-channel U-Net levels and mixed tiles: one wave group per kw tap
+    if (fa == 5 && fb == 5) return 4;
+    if (fa == 9 && fb == 5) return 5;
+    if (fa == 5 && fb == 8) return 6;
+    if (fa == 1 && fb == 8) return 7;
+    if (fa == 5 && fb == 1) return 8;
+    if (fa == 8 && fb == 4) return 9;
+    if (fa == 4 && fb == 8) return 10;
+  }
   return 0;
 }
 
@@ -660,7 +669,7 @@ extern "C" int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   if (nsplit_out) *nsplit_out = ns;
   const int64_t total = (int64_t)G.C * X.C * p->T[0] * p->T[1] * p->T[2];
-  return (ns + (ns > 64 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;
+  return (ns + (ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;
 }
 
 template <int FA, int FB, int WA, int WB>
@@ -689,7 +698,7 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   const size_t total_el = (size_t)G.C * X.C * ntaps;
-  const int nfold = ns > 64 ? (ns + WF_FOLD - 1) / WF_FOLD : 0;
+  const int nfold = ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0;  // serial split loops in the finish are latency-bound
   const size_t need = (size_t)(ns + nfold) * total_el * 4;
   if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   if (!dw) RG_FAIL(RG_ERR_BAD_SHAPE, "wgrad: null dw");
@@ -714,7 +723,14 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
     rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
     if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
     else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
-    else hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
+    else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
+    else if (kind == 4) hipLaunchKernelGGL((wgrad_kw_kernel<5, 5, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
+    else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
+    else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
+    else if (kind == 7) hipLaunchKernelGGL((wgrad_kw_kernel<1, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
+    else if (kind == 8) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
+    else if (kind == 9) hipLaunchKernelGGL((wgrad_kw_kernel<8, 4, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
+    else hipLaunchKernelGGL((wgrad_kw_kernel<4, 8, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
   } else if (wgrad_line_ok(p, fa, fb)) {
     WgradLineArgs la; la.w = a;
     la.wchunks = (a.RW + 31) / 32;
