@@ -64,7 +64,7 @@ typedef struct {
   int32_t dim0, dim1, K[3];
   int32_t swap;
   int32_t k0[3], kstep[3], ntap[3];
-  int32_t red_align; /* reduced-channel padding per tap: 32 or 64 = rg_conv3d_kalign(reduced, rows); 0 means 32 */
+  int32_t red_align; /* reduced-channel padding per tap: 8, 32 or 64 = rg_conv3d_kalign(reduced, rows); 0 means 32 */
 } rg_pack_params;
 /* K alignment per tap that rg_conv3d_igemm expects for a problem with `cin` reduced and `cout` produced channels */
 int rg_conv3d_kalign(int cin, int cout);

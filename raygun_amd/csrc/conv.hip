@@ -185,6 +185,98 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
   }
 }
 
+// ---- thin outputs (Cout <= 16): direct-fragment kernel ---------------------------------------------------------------
+// These layers (1/12-channel U-Net levels, 1x1x1 heads, 64->1 tails and the backward-data of 12->72 etc.) are HBM bound:
+// 16 output channels cannot feed a tile pipeline.  No LDS, no barrier: every wave loads its MFMA operands straight from
+// global memory in fragment layout — lane (row r = l&15, k-group g = l>>4) reads the 16 bytes (8 channel lanes) of voxel
+// row r for K-group 4*step+g; consecutive rows are consecutive voxels, so one wave-instruction covers 16 rows x 16..64
+// contiguous bytes per tap.  K is walked in 8-lane groups across taps (K = taps*lanes, no per-tap padding to 32), the
+// (tap -> offset) table sits in LDS, loads of step k+1 are in flight during the MFMAs of step k; occupancy hides the rest.
+struct GroupInfo { int off; short dd, dh, dw, pad; };
+template <int FM, bool CHECK>
+__global__ __launch_bounds__(256) void igemm_direct_kernel(IgemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) GroupInfo gtab[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gpt = a.cin_lanes >> 3;                 // 8-lane groups per tap
+  const int ntaps = a.TD * a.TH * a.TW;
+  const int ngroups = ntaps * gpt;
+  for (int G = tid; G < ngroups; G += 256) {
+    const int tap = G / gpt, c8 = G - tap * gpt;
+    const int kw = tap % a.TW, kh = (tap / a.TW) % a.TH, kd = tap / (a.TW * a.TH);
+    GroupInfo gi;
+    gi.dd = (short)(kd * a.ts[0]); gi.dh = (short)(kh * a.ts[1]); gi.dw = (short)(kw * a.ts[2]); gi.pad = 0;
+    gi.off = (int)(gi.dd * a.xsd + gi.dh * a.xsh + gi.dw * a.xsw) + c8 * 8;
+    gtab[G] = gi;
+  }
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  const long mw = (long)blockIdx.x * (64 * FM) + wave * (16 * FM);
+  int rd0[FM], rh0[FM], rw0[FM]; long rbase[FM]; bool rv[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const long m = mw + i * 16 + fr;
+    rv[i] = m < a.M;
+    long t = rv[i] ? m : 0;
+    const int rw = (int)(t % a.RW); t /= a.RW;
+    const int rh = (int)(t % a.RH); t /= a.RH;
+    const int rd = (int)(t % a.RD); t /= a.RD;
+    rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
+    rbase[i] = t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw;
+  }
+  const int krow = ngroups * 8;                      // packed weight row length (no padding)
+  const bf16_t* wrow = a.w + (long)fr * krow;
+  const int nsteps = (ngroups + 3) >> 2;
+  f32x4 acc[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 xf[FM], wf, xn[FM], wn;
+  auto fetch = [&](int ks, bf16x8 (&xo)[FM], bf16x8& wo) {
+    const int G = ks * 4 + fg;
+    const bool gv = G < ngroups;
+    const GroupInfo gi = gtab[gv ? G : 0];
+    wo = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (gv) wo = *(const bf16x8*)(wrow + G * 8);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      bool ok = gv & rv[i];
+      if (CHECK) ok = ok & ((unsigned)(rd0[i] + gi.dd) < (unsigned)a.ID) & ((unsigned)(rh0[i] + gi.dh) < (unsigned)a.IH) &
+                      ((unsigned)(rw0[i] + gi.dw) < (unsigned)a.IW);
+      xo[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) xo[i] = *(const bf16x8*)(a.x + rbase[i] + gi.off);
+    }
+  };
+  fetch(0, xf, wf);
+  for (int ks = 0; ks < nsteps; ++ks) {
+    if (ks + 1 < nsteps) fetch(ks + 1, xn, wn);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[i], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xf[i] = xn[i];
+    wf = wn;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const long m = mw + i * 16 + fr;
+    if (m >= a.M) continue;
+    long t = m;
+    const int rw = (int)(t % a.RW); t /= a.RW;
+    const int rh = (int)(t % a.RH); t /= a.RH;
+    const int rd = (int)(t % a.RD); t /= a.RD;
+    bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+                   (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+    const int c = fg * 4;
+    if (c >= a.cout_lanes) continue;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = 0.f;
+      if (c + r < a.cout) { v = acc[i][r] + (a.bias ? a.bias[c + r] : 0.f); v = act_fwd(v, a.act, a.slope); }
+      o[r] = (short)f2bf(v);
+    }
+    *(bf16x4*)(yrow + c) = o;
+  }
+}
+
 template <int BM, int FN>
 static void launch_igemm(const IgemmArgs& a, hipStream_t s) {
   constexpr int BN = FN * 16;
@@ -223,6 +315,36 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
     const void* z = zero_page();
     if (!z) RG_FAIL(RG_ERR_HIP, "conv: cannot resolve the zero page symbol");
     rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    RG_CHECK_LAUNCH();
+    return RG_OK;
+  }
+  if (rg_conv3d_kalign(X.C, p->cout) == 8) {  // thin output: direct-fragment kernel (packed K = taps*lanes, no padding)
+    IgemmArgs a;
+    a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
+    a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
+    a.RD = p->R[0]; a.RH = p->R[1]; a.RW = p->R[2];
+    a.TD = p->T[0]; a.TH = p->T[1]; a.TW = p->T[2];
+    bool check = false;
+    const int I[3] = {X.D, X.H, X.W};
+    for (int d = 0; d < 3; ++d) {
+      a.rs[d] = p->rstride[d]; a.tb[d] = p->tbase[d]; a.ts[d] = p->tstep[d]; a.os[d] = p->ostride[d]; a.oo[d] = p->ooffset[d];
+      const long lo0 = p->tbase[d], lo1 = p->tbase[d] + (long)p->tstep[d] * (p->T[d] - 1);
+      const long mn = lo0 < lo1 ? lo0 : lo1, mx = (lo0 < lo1 ? lo1 : lo0) + (long)(p->R[d] - 1) * p->rstride[d];
+      if (mn < 0 || mx >= I[d]) check = true;
+    }
+    a.xsn = X.sn; a.xsd = X.sd; a.xsh = X.sh; a.xsw = X.sw;
+    a.ysn = Y.sn; a.ysd = Y.sd; a.ysh = Y.sh; a.ysw = Y.sw;
+    a.cin32 = X.lanes; a.cin_lanes = X.lanes; a.cout = p->cout; a.cout_lanes = Y.lanes; a.wrows = 16;
+    a.act = p->act; a.slope = p->slope;
+    a.M = (long)X.N * a.RD * a.RH * a.RW;
+    const int ngroups = a.TD * a.TH * a.TW * (X.lanes / 8);
+    const size_t shm = (size_t)ngroups * sizeof(GroupInfo);
+    if (shm > 64 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: tap table of %d groups does not fit LDS", ngroups);
+    if ((long)X.N * X.sn >= 0x7fffffffL) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: input larger than 2^31 elements");
+    dim3 grid((unsigned)((a.M + 255) / 256));
+    rg_set_kernel_name("igemm_direct_kernel<4,%d>", (int)check);
+    if (check) hipLaunchKernelGGL((igemm_direct_kernel<4, true>), grid, dim3(256), shm, (hipStream_t)s, a);
+    else hipLaunchKernelGGL((igemm_direct_kernel<4, false>), grid, dim3(256), shm, (hipStream_t)s, a);
     RG_CHECK_LAUNCH();
     return RG_OK;
   }

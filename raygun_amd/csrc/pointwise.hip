@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_
     __syncthreads();
   }
 }
-static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : 32; }
+static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : (p->red_align == 8 ? 8 : 32); }
 static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
-  if (!p || p->dim0 <= 0 || p->dim1 <= 0 || (p->red_align != 0 && p->red_align != 32 && p->red_align != 64)) return -1;
+  if (!p || p->dim0 <= 0 || p->dim1 <= 0 || (p->red_align != 0 && p->red_align != 8 && p->red_align != 32 && p->red_align != 64)) return -1;
   for (int d = 0; d < 3; ++d) {
     if (p->K[d] <= 0 || p->ntap[d] <= 0 || p->k0[d] < 0 || p->kstep[d] <= 0) return -1;
     if (p->k0[d] + p->kstep[d] * (p->ntap[d] - 1) >= p->K[d]) return -1;
