@@ -100,6 +100,31 @@ def build_cyclegan(dev, size, seed):
     return step, dict(model="CycleGAN link: ResNet(ngf64,6 blocks,2 down,IN)+PatchD(ngf64,3 layers) lsgan", params=71848196)
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summaries (profiles/*_pmc_{fetch,write}_size.csv,
+    separate --pmc passes).  FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
+    tallies 128-byte read requests at 64 B).  None when no profile names this kernel."""
+    import csv
+    import glob
+    key = kernel_name.split("<")[0]
+    args = kernel_name[len(key):].strip("<>").split(",") if "<" in kernel_name else []
+    out = {}
+    for kind, scale in (("fetch", 2.0 * 1024), ("write", 1024.0)):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}_size.csv")))
+        if not files:
+            return None
+        best = None
+        for r in csv.DictReader(open(files[-1])):
+            nm = r["kernel"].replace("void ", "").replace(" ", "").replace("true", "1").replace("false", "0")
+            if nm.startswith(key + "<" + ",".join(args)) or (not args and nm.startswith(key)):
+                best = float(r["mean_per_dispatch"]) * scale
+                break
+        if best is None:
+            return None
+        out[kind] = best
+    return out["fetch"] + out["write"]
+
+
 def cpu_baseline(workload, size):
     """The oracle (plain PyTorch fp32 restatement) timed on this host's cores for one step on a bounded sample."""
     from oracle import torch_ref as O
@@ -176,7 +201,8 @@ def main():
     if dom:
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(dom[0]) if a.workload == "unet" else None,
+                        traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_pmc_*.csv passes of this workload",
                         launches_per_step=dom[1]["launches"] // a.steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
     flop = (UNET_FLOP_PER_STEP if a.workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if a.workload == "unet" else 128)) ** 3
     res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if a.workload == "unet" else "CycleGAN 128^3 train-step ms",
@@ -190,7 +216,7 @@ def main():
                roofline=roofline, kernels=kernels)
     if world == 1 and not a.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_size or (132 if a.workload == "unet" else 32))
+            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_size or (196 if a.workload == "unet" else 48))
         except Exception as e:  # the baseline is reported, never the product path
             res["cpu_baseline"] = dict(error=repr(e))
     print(json.dumps(res), flush=True)
