@@ -13,6 +13,7 @@
 //     ((row>>3)&1)<<1, which makes every ds_read_b128 lane group hit 16 distinct slots;
 //   * double-buffered LDS, register prefetch of the next K-step, one barrier per step.
 #include "common.h"
+#include <stdlib.h>
 
 struct IgemmArgs {
   const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
@@ -288,6 +289,9 @@ static void launch_igemm(const IgemmArgs& a, hipStream_t s) {
 extern "C" int rg_conv3d_kalign(int cin, int cout);
 int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p,
                      const void* zeros, hipStream_t st);
+int rg_launch_igemm3(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p,
+                     const void* zeros, hipStream_t st);
+bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
 static const void* zero_page() {
   static const void* cache[64] = {nullptr};
@@ -314,7 +318,8 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
   if (rg_conv3d_kalign(X.C, p->cout) == 64) {
     const void* z = zero_page();
     if (!z) RG_FAIL(RG_ERR_HIP, "conv: cannot resolve the zero page symbol");
-    rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    if (rg_igemm3_ok(X, p) && !getenv("RG_NO_IGEMM3")) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    else rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     RG_CHECK_LAUNCH();
     return RG_OK;
   }
