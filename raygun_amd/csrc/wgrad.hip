@@ -422,13 +422,25 @@ static bool wgrad_line_ok(const rg_conv_params* p, int fa, int fb) {
 }
 
 // ---- wide layers, line-aligned K-steps with kw reuse --------------------------------------------------------------
-// The flat kernel above is bound by the global->LDS path (measured ~25-30 GB/s per CU): a 144x144 tile moves 18.4 KB per
-// 32-row step for ONE tap (72 FLOP/B).  Here a K-step is 32 consecutive voxels of one output line and the workgroup owns
-// ALL TW taps of one (kd,kh): the X line segment (32+TW-1 rows) is staged once and read at row offsets 0..TW-1 by the
-// transposing LDS reads, the G tile once for TW taps: ~TW times the FLOP per byte (216 FLOP/B for 3x3x3 at 144x144,
-// 206 for the 7^3 64x64 layer).  Cost: lines are padded to multiples of 32 rows (host picks this kernel when that
-// wastes less than half the MFMA work).  Wave (wa, wb) owns an IAxIB block of 16x16 fragments for every kw.
-struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; };
+// The flat kernel above is bound by the global->LDS path: a 144x144 tile moves 18.4 KB per 32-row step for ONE tap
+// (72 FLOP/B).  Here a K-step is 32 consecutive voxels of one output line and the workgroup owns ALL TW taps of one
+// (kd,kh): the X line segment (32+TW-1 rows) is staged once and read at row offsets 0..TW-1 by the transposing LDS reads,
+// the G tile once for TW taps: ~TW times the FLOP per byte (216 FLOP/B for 3x3x3 at 144x144, 206 for the 7^3 64x64
+// layer).  Wave (wa, wb) owns an IAxIB block of 16x16 fragments for every kw.
+//
+// Two row orders (host picks the one with fewer padded rows, wgrad_kw_geom):
+//  line: a unit is a 32-voxel chunk of one output line; lines are padded to multiples of 32 rows.
+//  flat: valid stride-1 convs over dense X planes.  Output voxels are numbered in the INPUT pitch, o = h*IW + w, so
+//        tap (kh,kw) is the pure shift o + kh*IW + kw over the whole (h,w) plane: the plane is one long line, padded once
+//        (17x17 outputs of a 19x19 plane: 82 % useful rows instead of 53 %).  G rows with w >= RW are masked to zero.
+//
+// The load path is what bounds this kernel (9 waves x ~300 VALU address instructions per step made SIMD0 the
+// bottleneck: measured 4.3 of 5.0 ms with the MFMAs removed), so every piece's byte offset inside its line/plane is a
+// per-thread constant, the per-step part is wave-uniform (SGPR base in a buffer descriptor whose num_records does the
+// bounds check: out-of-range rows read as zero), and the unit -> (n, d, h, chunk) decode is incremental.
+struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; int flat; unsigned pmagic; int exp; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define WG_OOB 0x80000000u  // voffset of a piece that loads nothing: stays >= num_records (< 2^30) after any per-step add
 
 template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP>
 __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
@@ -439,8 +451,7 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   constexpr int SA = wg_pad(TA), SB = wg_pad(TB);
   constexpr int CA = TA / 8, CB = TB / 8;
   constexpr int XR = 32 + TWM - 1;
-  constexpr int NCH = 32 * CA + XR * CB;
-  constexpr int PER_T = (NCH + NT - 1) / NT;
+  constexpr int PER_G = (32 * CA + NT - 1) / NT, PER_X = (XR * CB + NT - 1) / NT;
   constexpr int IA = FA / WA, IB = FB / WB;
   static_assert(FA % WA == 0 && FB % WB == 0, "wave layout must divide the tile");
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (32 * SA + XR * SB)];
@@ -453,15 +464,25 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   const int xrows = 32 + a.TW - 1;
   const long ubeg = (long)blockIdx.z * p.units_per_split;
   long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
+  const int gsw2 = (int)a.gsw * 2, gsh2 = (int)a.gsh * 2, xsw2 = (int)a.xsw * 2;
 
-  // fixed per-thread chunk list: code = isX<<16 | row<<8 | chunk ; -1 = none
-  int lc[PER_T];
+  // per-thread piece tables: byte offset inside the line/plane at chunk 0, LDS element offset in buffer 0 (-1: no piece)
+  unsigned gv[PER_G], xv[PER_X];
+  int gl[PER_G], grow[PER_G], xl[PER_X];
 #pragma unroll
-  for (int k = 0; k < PER_T; ++k) {
-    const int q = tid + NT * k;
-    lc[k] = -1;
-    if (q < 32 * CA) lc[k] = ((q / CA) << 8) | (q % CA);
-    else if (q < 32 * CA + xrows * CB) { const int q2 = q - 32 * CA; lc[k] = (1 << 16) | ((q2 / CB) << 8) | (q2 % CB); }
+  for (int k = 0; k < PER_G; ++k) {
+    const int q = tid + NT * k, row = q / CA, ch = q % CA, c = a0 + ch * 8;
+    const bool exists = q < 32 * CA;
+    gl[k] = exists ? row * SA + ch * 8 : -1;
+    grow[k] = row;
+    gv[k] = (exists && c < a.alanes) ? (unsigned)((p.flat ? 0 : row * gsw2) + c * 2) : WG_OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < PER_X; ++k) {
+    const int q = tid + NT * k, row = q / CB, ch = q % CB, c = b0 + ch * 8;
+    const bool exists = q < xrows * CB;
+    xl[k] = exists ? row * SB + ch * 8 : -1;
+    xv[k] = (exists && c < a.blanes) ? (unsigned)(row * xsw2 + c * 2) : WG_OOB;
   }
   f32x4 acc[TPW][IA][IB];
 #pragma unroll
@@ -471,44 +492,52 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
 #pragma unroll
       for (int j = 0; j < IB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 regs0[PER_T], regs1[DEEP ? PER_T : 1];  // DEEP: two K-steps in flight through the registers
-  auto gload = [&](bf16x8 (&regs)[PER_T], long u) {
-    unsigned t = (unsigned)u;
-    const int wc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
-    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
-    const int rd = (int)(t % (unsigned)a.RD); const long n = t / (unsigned)a.RD;
-    const int w0 = wc * 32;
-    const long gline = n * a.gsn + rd * a.gsd + rh * a.gsh;
-    const int id = rd * a.rs[0] + a.tb[0] + kd * a.ts[0], ih = rh * a.rs[1] + a.tb[1] + kh * a.ts[1];
-    const bool line_ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
-    const long xline = n * a.xsn + (long)id * a.xsd + (long)ih * a.xsh;
-    const int iw0 = w0 + a.tb[2];
+  // load cursor (wave-uniform): unit -> (n, rd, rh, wc); flat units have no rh
+  const int rhe = p.flat ? 1 : a.RH;
+  int cwc, crh, crd, cn;
+  {
+    unsigned t = (unsigned)ubeg;
+    cwc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+    crh = (int)(t % (unsigned)rhe); t /= (unsigned)rhe;
+    crd = (int)(t % (unsigned)a.RD); cn = (int)(t / (unsigned)a.RD);
+  }
+  struct Staged { u32x4 g[PER_G], x[PER_X]; };
+  auto gload = [&](Staged& r) {  // loads the unit under the cursor, then advances the cursor
+    const int w0 = cwc * 32;
+    const int id = crd * a.rs[0] + a.tb[0] + kd * a.ts[0];
+    const bf16_t* gbase; const bf16_t* xbase; int nrecg, nrecx, gadd, xadd;
+    if (p.flat) {
+      const bool ok = (unsigned)id < (unsigned)a.ID;
+      gbase = a.g + cn * a.gsn + crd * a.gsd; nrecg = a.RH * gsh2; gadd = 0;
+      xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd : a.x; nrecx = ok ? a.IH * a.IW * xsw2 : 0;
+      xadd = ((a.tb[1] + kh) * a.IW + a.tb[2] + w0) * xsw2;
+    } else {
+      const int ih = crh * a.rs[1] + a.tb[1] + kh * a.ts[1];
+      const bool ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
+      gbase = a.g + cn * a.gsn + crd * a.gsd + crh * a.gsh; nrecg = a.RW * gsw2; gadd = w0 * gsw2;
+      xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd + (long)ih * a.xsh : a.x; nrecx = ok ? a.IW * xsw2 : 0;
+      xadd = (w0 + a.tb[2]) * xsw2;
+    }
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, (short)0, nrecg, 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, nrecx, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < PER_T; ++k) {
-      bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      const int code = lc[k];
-      if (code >= 0) {
-        const int row = (code >> 8) & 255, ch = code & 255;
-        if (code >> 16) {
-          const int c = b0 + ch * 8, iw = iw0 + row;
-          if (line_ok && c < a.blanes && (unsigned)iw < (unsigned)a.IW) v = *(const bf16x8*)(a.x + xline + (long)iw * a.xsw + c);
-        } else {
-          const int c = a0 + ch * 8;
-          if (w0 + row < a.RW && c < a.alanes) v = *(const bf16x8*)(a.g + gline + (long)(w0 + row) * a.gsw + c);
-        }
+    for (int k = 0; k < PER_G; ++k) {
+      unsigned vo = gv[k] + (unsigned)gadd;
+      if (p.flat) {  // o = h*IW + w in the input pitch; rows with w >= RW (or past the plane) carry no gradient
+        const unsigned o = (unsigned)(w0 + grow[k]), h = __umulhi(o, p.pmagic), w = o - h * (unsigned)a.IW;
+        vo = (w < (unsigned)a.RW && h < (unsigned)a.RH) ? gv[k] + h * (unsigned)gsh2 + w * (unsigned)gsw2 : WG_OOB;
       }
-      regs[k] = v;
+      r.g[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)vo, 0, 0);
     }
-  };
-  auto lstore = [&](bf16x8 (&regs)[PER_T], int buf) {
 #pragma unroll
-    for (int k = 0; k < PER_T; ++k) {
-      const int code = lc[k];
-      if (code < 0) continue;
-      const int row = (code >> 8) & 255, ch = code & 255;
-      if (code >> 16) *(bf16x8*)(Xs + (buf * XR + row) * SB + ch * 8) = regs[k];
-      else *(bf16x8*)(Gs + (buf * 32 + row) * SA + ch * 8) = regs[k];
-    }
+    for (int k = 0; k < PER_X; ++k) r.x[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xv[k] + (unsigned)xadd), 0, 0);
+    if (++cwc == p.wchunks) { cwc = 0; if (++crh == rhe) { crh = 0; if (++crd == a.RD) { crd = 0; ++cn; } } }
+  };
+  auto lstore = [&](const Staged& r, int buf) {
+#pragma unroll
+    for (int k = 0; k < PER_G; ++k) if (gl[k] >= 0) *(u32x4*)(Gs + buf * 32 * SA + gl[k]) = r.g[k];
+#pragma unroll
+    for (int k = 0; k < PER_X; ++k) if (xl[k] >= 0) *(u32x4*)(Xs + buf * XR * SB + xl[k]) = r.x[k];
   };
 
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
@@ -540,28 +569,30 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   };
   if constexpr (DEEP) {
     // step u's operands sit in registers two steps ahead; LDS is double-buffered, one barrier per step
-    if (ubeg < uend) gload(regs0, ubeg);
-    if (ubeg + 1 < uend) gload(regs1, ubeg + 1);
+    Staged r0, r1;
+    if (ubeg < uend) gload(r0);
+    if (ubeg + 1 < uend) gload(r1);
     for (long u = ubeg; u < uend; u += 2) {
-      lstore(regs0, 0);
+      lstore(r0, 0);
       __syncthreads();
-      if (u + 2 < uend) gload(regs0, u + 2);
+      if (u + 2 < uend) gload(r0);
       compute(0);
       if (u + 1 < uend) {
-        lstore(regs1, 1);
+        lstore(r1, 1);
         __syncthreads();
-        if (u + 3 < uend) gload(regs1, u + 3);
+        if (u + 3 < uend) gload(r1);
         compute(1);
       }
     }
   } else {
-    if (ubeg < uend) gload(regs0, ubeg);
+    Staged r0;
+    if (ubeg < uend) gload(r0);
     int buf = 0;
     for (long u = ubeg; u < uend; ++u, buf ^= 1) {
-      lstore(regs0, buf);
+      lstore(r0, buf);
       __syncthreads();
-      if (u + 1 < uend) gload(regs0, u + 1);
-      compute(buf);
+      if (u + 1 < uend && !(p.exp & 1)) gload(r0);
+      if (!(p.exp & 2)) compute(buf);
     }
   }
 
@@ -585,11 +616,28 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
       }
   }
 }
+// row order and unit count of the kw-reuse kernel for this problem; false = not eligible
+struct KwGeom { int flat; int wchunks; long units; };
+static bool wgrad_kw_geom(const CL5& G, const CL5& X, const rg_conv_params* p, KwGeom* o) {
+  if (p->rstride[2] != 1 || p->tstep[2] != 1 || p->T[2] < 2) return false;
+  if ((long)X.H * X.sh * 2 >= (1L << 30) || (long)G.H * G.sh * 2 >= (1L << 30)) return false;  // 32-bit buffer offsets
+  const int rw = p->R[2], rh = p->R[1];
+  const long line_rows = (long)rh * round_up(rw, 32);
+  bool flat_ok = p->rstride[1] == 1 && p->tstep[1] == 1 && X.sh == (long)X.W * X.sw && p->tbase[1] >= 0 &&
+                 p->tbase[1] + p->T[1] - 1 + rh - 1 <= X.H - 1 && p->tbase[2] >= 0 && p->tbase[2] + p->T[2] - 1 + rw - 1 <= X.W - 1 &&
+                 (double)X.H * X.W * X.W < 4.0e9;  // exact division by IW through the 32-bit magic multiply
+  const long flat_rows = ((long)(rh - 1) * X.W + rw + 31) / 32 * 32;
+  const bool flat = flat_ok && flat_rows < line_rows;
+  const long rows = flat ? flat_rows : line_rows;
+  if ((long)rh * rw * 2 < rows) return false;  // padding would waste more than half the MFMA work
+  o->flat = flat;
+  o->wchunks = flat ? (int)(flat_rows / 32) : (rw + 31) / 32;
+  o->units = (long)G.N * p->R[0] * (flat ? 1 : rh) * o->wchunks;
+  return true;
+}
 // which (FA, FB) tiles have a kw-reuse instantiation, and for how many W taps
-static int wgrad_kw_kind(const rg_conv_params* p, int fa, int fb) {
-  if (p->rstride[2] != 1 || p->tstep[2] != 1 || p->T[2] < 2) return 0;
-  const int rw = p->R[2];
-  if (rw * 2 < round_up(rw, 32)) return 0;  // lines padded to 32 rows would waste more than half the MFMA work
+static int wgrad_kw_kind(const CL5& G, const CL5& X, const rg_conv_params* p, int fa, int fb, KwGeom* geom) {
+  if (!wgrad_kw_geom(G, X, p, geom)) return 0;
   if (fa == 9 && fb == 9 && p->T[2] <= 3) return 1;
   if (fa == 4 && fb == 4 && p->T[2] <= 8) return 2;
   if (fa == 8 && fb == 8 && p->T[2] <= 4) return 3;
@@ -622,11 +670,11 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
   if (*fa == 1 && *fb == 1) tiles = (ntaps + WT_TMAX - 1) / WT_TMAX;  // wgrad_thin_kernel: all taps in one workgroup
-  if (wgrad_kw_kind(p, *fa, *fb)) {  // wgrad_kw_kernel: split over (line, 32-voxel chunk) units
-    const long wch = (p->R[2] + 31) / 32;
-    const long units = (long)G.N * p->R[0] * p->R[1] * wch;
+  KwGeom kg;
+  if (const int kind = wgrad_kw_kind(G, X, p, *fa, *fb, &kg)) {  // wgrad_kw_kernel: split over 32-row units
+    const long units = kg.units;
     const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
-    const long target = wgrad_kw_kind(p, *fa, *fb) == 3 ? 768 : 1536;  // workgroups aimed at (measured per tile shape)
+    const long target = kind == 3 ? 768 : 1536;  // workgroups aimed at (measured per tile shape)
     long ns = (target + tl - 1) / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
     const long ups = (units + ns - 1) / ns;
     *nsplit = (int)((units + ups - 1) / ups);
@@ -713,12 +761,14 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   a.A = G.C; a.B = X.C; a.alanes = G.lanes; a.blanes = X.lanes;
   a.M = (long)G.N * a.RD * a.RH * a.RW; a.rows_per_split = rps; a.nsplit = ns;
   hipStream_t st = (hipStream_t)s;
-  if (const int kind = wgrad_kw_kind(p, fa, fb)) {
+  KwGeom kg;
+  if (const int kind = wgrad_kw_kind(G, X, p, fa, fb, &kg)) {
     WgradKwArgs ka; ka.w = a;
-    ka.wchunks = (a.RW + 31) / 32;
-    ka.units = (long)G.N * a.RD * a.RH * ka.wchunks;
+    ka.wchunks = kg.wchunks; ka.units = kg.units; ka.flat = kg.flat;
+    ka.pmagic = (unsigned)((1ULL << 32) / (unsigned)X.W + 1);
     ka.units_per_split = rps;
     ka.nta = (a.A + fa * 16 - 1) / (fa * 16); ka.ntb = (a.B + fb * 16 - 1) / (fb * 16);
+    { const char* e = getenv("RG_EXP"); ka.exp = e ? atoi(e) : 0; }
     dim3 grid(ka.nta * ka.ntb, a.TD * a.TH, ns);
     rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
     if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);

@@ -82,6 +82,10 @@ CONV_CASES = [
     (64, 64, 7, 1, 0, (8, 9, 26), "none"),
     (128, 128, 4, 1, 1, (4, 5, 33), "leaky"),
     (128, 128, 3, 1, 1, (3, 3, 18), "none"),
+    # same kernel, flat row order (valid stride-1 conv over dense planes: the (h,w) plane walked as one line in the input pitch)
+    (144, 144, 3, 1, 0, (4, 19, 19), "relu"),
+    (64, 64, 7, 1, 0, (8, 30, 30), "none"),
+    (80, 72, 3, 1, 0, (5, 23, 37), "none"),
 ]
 
 
