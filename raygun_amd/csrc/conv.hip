@@ -292,6 +292,9 @@ int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const flo
 int rg_launch_igemm3(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p,
                      const void* zeros, hipStream_t st);
 bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
+bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p);
+int rg_igemm4_tile_n(int cout);
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
 static const void* zero_page() {
   static const void* cache[64] = {nullptr};
@@ -318,7 +321,11 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
   if (rg_conv3d_kalign(X.C, p->cout) == 64) {
     const void* z = zero_page();
     if (!z) RG_FAIL(RG_ERR_HIP, "conv: cannot resolve the zero page symbol");
-    if (rg_igemm3_ok(X, p) && !getenv("RG_NO_IGEMM3")) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    // igemm4 (activations straight into fragments) for 128/144-channel tiles; the kw-reuse kernel keeps the unpadded
+    // 128-channel stride-1 layers (787 vs 731 TFLOP/s) and both LDS kernels the narrow tiles
+    const bool i3 = rg_igemm3_ok(X, p);
+    if (rg_igemm4_ok(X, p) && !(i3 && rg_igemm4_tile_n(p->cout) == 8)) rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s);
+    else if (i3) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     else rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     RG_CHECK_LAUNCH();
     return RG_OK;

@@ -1,0 +1,300 @@
+// igemm4 — wide-channel implicit-GEMM convolution, activations straight into MFMA fragments (no LDS round trip).
+//
+// Measured on igemm2 (128x144 tile, 4 waves, both operands through LDS): with the global loads, the MFMAs and the address
+// arithmetic all removed the loop still took 58 % of its time — the LDS itself.  ds_write_b128 moves 1 KiB per ~13 cycles
+// (79 B/clk/CU), so the 36 stores + 88 fragment reads of one tile step cost ~820 LDS cycles against 576 MFMA cycles per
+// wave.  But every wave of that kernel only ever multiplies the activation rows it loaded itself: the LDS trip of the
+// activation operand is pure overhead.  The B operand of v_mfma_f32_16x16x32_bf16 wants, per lane (voxel n = l&15,
+// k-group g = l>>4), 8 consecutive channels of voxel n — 16 contiguous bytes of a channels-last tensor.  So here
+//   * each lane loads its fragment pieces of the activation tile directly (buffer_load_dwordx4, 16 rows x 64 B per
+//     wave-instruction), half a K-step ahead in a single register set; out-of-volume taps, rows past M and lanes past Cin turn the
+//     byte offset into an out-of-range one and the buffer descriptor returns zeros (branch-free zero padding);
+//   * only the weight tile (shared by the 4 waves) goes through LDS, register-staged and double-buffered as in igemm2,
+//     its per-step address a wave-uniform SGPR offset on a per-thread constant;
+//   * same tile order (XCD-aware), K order (channel chunk outer, tap inner), swizzle, hand-counted fragment reads,
+//     packed-weight format and epilogue as igemm2.
+// LDS work per tile step drops to 18 stores + 72 reads, VALU address work from ~90 to ~25 instructions per wave-step.
+#include "common.h"
+#include <utility>
+#include <stdlib.h>
+
+template <class F, int... Is>
+__device__ __forceinline__ void s4_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void s4for(F&& f) { s4_impl(f, std::make_integer_sequence<int, N>{}); }
+
+struct Igemm4Args {
+  const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
+  int N, ID, IH, IW;
+  int RD, RH, RW;
+  int TD, TH, TW;
+  int rs[3], tb[3], ts[3], os[3], oo[3];
+  long xsn, xsd, xsh, xsw;
+  long ysn, ysd, ysh, ysw;
+  int cink, cin_lanes, cout, cout_lanes, wrows;
+  int act; float slope;
+  long M;
+  int tiles_m, tiles_n;
+  unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
+};
+
+typedef __attribute__((address_space(3))) void* lptr4_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void ld4_16(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+template <int N>
+__device__ __forceinline__ void ld4_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+#define IG4_OOB 0x80000000u
+
+template <int FM, int FN, bool CHECK>
+__global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Args a) {
+  constexpr int BM = 64 * FM, BN = FN * 16;
+  constexpr int BPIECES = ((BN / 8) + 3) / 4 * 4, BROWS = BPIECES * 8, BPW = BPIECES / 4;
+  constexpr int BSTAGE = BROWS * 64;  // bf16 elements per weight stage
+  __shared__ __attribute__((aligned(128))) bf16_t lds[2 * BSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = a.tiles_m * a.tiles_n;
+  int bid = blockIdx.x;
+  { const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+  const int tile_n = bid / a.tiles_m, tile_m = bid % a.tiles_m;
+  const long m0 = (long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int fr = lane & 15, fg = lane >> 4, fsw = fr >> 1;
+  const int lrow = lane >> 3, lslot = lane & 7;
+
+  // ---- the FM activation rows of this lane (fragment i, voxel fr), as byte offsets into x
+  int rd0[FM], rh0[FM], rw0[FM]; unsigned rbase[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const long m = m0 + wave * (16 * FM) + i * 16 + fr;
+    const bool v = m < a.M;
+    long t = v ? m : 0;
+    const int rw = (int)(t % a.RW); t /= a.RW;
+    const int rh = (int)(t % a.RH); t /= a.RH;
+    const int rd = (int)(t % a.RD); t /= a.RD;
+    rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
+    // tap offsets are added later and may be negative: keep the sum inside [0, 2^31) for valid lanes, park invalid rows
+    rbase[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + fg * 8) * 2) : IG4_OOB;
+    if (!v) { rd0[i] = rh0[i] = rw0[i] = -(1 << 20); }
+  }
+  // ---- the BPW weight pieces of this lane: per-thread constant byte offset (row, swizzled slot); the tap/chunk part is
+  // wave-uniform and rides in the instruction's SGPR offset (not range-checked, so it is only ever applied to valid steps)
+  const int ntaps = a.TD * a.TH * a.TW;
+  unsigned wv[BPW];
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) {
+    const int piece = wave * BPW + i, row = piece * 8 + lrow, n = n0 + row;
+    const bool v = row < BN && n < a.wrows;
+    const int slot = lslot ^ ((piece & 1) * 4 + (lrow >> 1));
+    wv[i] = v ? (unsigned)(((long)n * ntaps * a.cink + slot * 8) * 2) : IG4_OOB;
+  }
+  const int nchunk = a.cink >> 6;
+  const int nk = ntaps * nchunk;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.xbytes, 0x00020000);
+  const auto rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.wbytes, 0x00020000);
+
+  // ---- producer odometers (the K-step whose loads are issued next): channel chunk OUTER, tap INNER.  The weights run
+  // two steps ahead (registers, then LDS), the activation fragments one (registers only)
+  int pchunk = 0, kd = 0, kh = 0, kw = 0;  // activations
+  int btap = 0, bchunk = 0;                // weights
+  auto advance_a = [&]() {
+    ++kw;
+    const int cw = kw == a.TW; kw = cw ? 0 : kw; kh += cw;
+    const int ch = kh == a.TH; kh = ch ? 0 : kh; kd += ch;
+    const int cd = kd == a.TD; kd = cd ? 0 : kd; pchunk += cd;
+  };
+  auto advance_b = [&]() { ++btap; const int c = btap == ntaps; btap = c ? 0 : btap; bchunk += c; };
+  u32x4_t sb[BPW];  // one stage of weights in flight through the registers
+  auto load_b = [&]() {
+    const bool ok = bchunk < nchunk;
+    const int so = ok ? (btap * a.cink + bchunk * 64) * 2 : 0;
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw_, (int)(ok ? wv[i] : IG4_OOB), so, 0);
+    advance_b();
+  };
+  // activation fragments live in ONE register set: the k-half 0 pieces of step ks+1 are loaded once the k-half 0
+  // MFMAs of step ks have issued (mid-step), the k-half 1 pieces at the end of the step — half a step of latency cover
+  // each (>= 288 MFMA cycles per wave, times the waves sharing the SIMD) for half the registers of a double buffer
+  u32x4_t xa[FM][2];
+  unsigned vo0[FM], vo1[FM];
+  auto prep_a = [&]() {
+    const int od = kd * a.ts[0], oh = kh * a.ts[1], ow = kw * a.ts[2];
+    const int tapoff = ((int)(od * a.xsd + oh * a.xsh + ow * a.xsw) + pchunk * 64) * 2;
+    const int c = pchunk * 64 + fg * 8;
+    const bool c0 = c < a.cin_lanes, c1 = c + 32 < a.cin_lanes;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      bool ok = true;  // rows past M were parked at IG4_OOB (no tap offset brings them back: |tapoff| < 2^30)
+      if (CHECK) ok = ((unsigned)(rd0[i] + od) < (unsigned)a.ID) & ((unsigned)(rh0[i] + oh) < (unsigned)a.IH) & ((unsigned)(rw0[i] + ow) < (unsigned)a.IW);
+      const unsigned vo = rbase[i] + (unsigned)tapoff;
+      vo0[i] = (ok & c0) ? vo : IG4_OOB;
+      vo1[i] = (ok & c1) ? vo + 64u : IG4_OOB;
+    }
+    advance_a();
+  };
+  auto load_a0 = [&]() {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xa[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo0[i], 0, 0);
+  };
+  auto load_a1 = [&]() {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) xa[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo1[i], 0, 0);
+  };
+  auto store_b = [&](int buf) {
+    bf16_t* Bs = lds + buf * BSTAGE + lane * 8;
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) *(u32x4_t*)(Bs + (wave * BPW + i) * 512) = sb[i];
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: stage 0 weights -> LDS buffer 0, stage 1 weights in registers; activations of stage 0 in flight
+  load_b(); prep_a(); load_a0(); load_a1();
+  store_b(0);
+  load_b();
+
+  const unsigned lds0 = (unsigned)(size_t)(lptr4_t)lds;
+  const unsigned b_lane = lds0 + fr * 128 + ((fg ^ fsw) << 4);
+  constexpr int T2 = 2 * FN;
+  int stage = 0;
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my weight stores of this stage (issued last step) are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    store_b(stage ^ 1);           // weights of step ks+1: registers -> the buffer whose readers finished before the barrier
+    load_b();                     // weights of step ks+2 -> registers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // keep the hand-counted fragment reads alone on the counter
+    const unsigned b0 = b_lane + stage * (BSTAGE * 2), b1 = b0 ^ 64u;
+    bf16x8 wf[3];
+    ld4_16<0>(wf[0], b0);
+    ld4_16<2048>(wf[1], b0);
+    s4for<T2>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      constexpr int kk = t / FN, j = t % FN;
+      if constexpr (t + 2 < T2) {
+        constexpr int k2 = (t + 2) / FN, j2 = (t + 2) % FN;
+        ld4_16<j2 * 2048>(wf[(t + 2) % 3], k2 ? b1 : b0);
+      }
+      constexpr int NW = (t + 1 < T2) + (t + 2 < T2);
+      ld4_wait<NW>(wf[t % 3]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bf16x8 xf;
+        __builtin_memcpy(&xf, &xa[i][kk], 16);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t % 3], xf, acc[i][j], 0, 0, 0);
+      }
+      if constexpr (t == FN - 1) { prep_a(); load_a0(); }  // k-half 0 fragments are free: fetch those of step ks+1
+    });
+    load_a1();
+    stage ^= 1;
+  }
+
+  // ---- epilogue: lane holds channels c..c+3 of voxel (lane&15) for every fragment
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const long m = m0 + wave * (16 * FM) + i * 16 + fr;
+    if (m >= a.M) continue;
+    long t = m;
+    const int rw = (int)(t % a.RW); t /= a.RW;
+    const int rh = (int)(t % a.RH); t /= a.RH;
+    const int rd = (int)(t % a.RD); t /= a.RD;
+    bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+                   (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = n0 + j * 16 + fg * 4;
+      if (c >= a.cout_lanes) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (c + r < a.cout) {
+          v = acc[i][j][r] + (a.bias ? a.bias[c + r] : 0.f);
+          v = act_fwd(v, a.act, a.slope);
+        }
+        o[r] = (short)f2bf(v);
+      }
+      *(bf16x4*)(yrow + c) = o;
+    }
+  }
+}
+
+template <int FM, int FN>
+static void launch_igemm4(Igemm4Args& a, bool check, hipStream_t s) {
+  constexpr int BM = 64 * FM, BN = FN * 16;
+  a.tiles_m = (int)((a.M + BM - 1) / BM);
+  a.tiles_n = (a.cout_lanes + BN - 1) / BN;
+  rg_set_kernel_name("igemm4_kernel<%d,%d,%d>", FM, FN, (int)check);
+  if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((igemm4_kernel<FM, FN, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+}
+
+// extent in elements of a channels-last view (last addressable lane + 1)
+static long cl5_extent(const CL5& T) {
+  return (long)(T.N - 1) * T.sn + (long)(T.D - 1) * T.sd + (long)(T.H - 1) * T.sh + (long)(T.W - 1) * T.sw + T.lanes;
+}
+
+static int ig4_fn(int nf) {
+  if (nf % 9 == 0) return 9;
+  if (nf % 8 == 0) return 8;
+  if (nf <= 5) return nf < 4 ? 4 : nf;
+  if (nf % 5 == 0) return 5;
+  return (round_up(nf, 9) - nf) * 8 <= (round_up(nf, 8) - nf) * 9 ? 9 : 8;
+}
+// Wide output tiles only (128/144 channels): a 64/80-channel tile issues one 1-KiB activation load per 4-5 MFMAs and the
+// texture path, not the LDS, becomes the limit (measured 570 vs 613-741 TFLOP/s for igemm2/igemm3 on 64-channel layers).
+bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p) {
+  if (ig4_fn(round_up(p->cout, 16) / 16) < 8) return false;
+  const long wel = (long)round_up(p->cout, 16) * p->T[0] * p->T[1] * p->T[2] * round_up(X.C, 64);
+  // byte offsets are 32-bit and a parked lane sits at 2^31 -/+ one tap offset: everything addressable must stay below 2^30
+  return cl5_extent(X) * 2 < (1L << 30) && wel * 2 < (1L << 30);
+}
+int rg_igemm4_tile_n(int cout) { return ig4_fn(round_up(cout, 16) / 16); }
+
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st) {
+  Igemm4Args a;
+  a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
+  a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
+  a.RD = p->R[0]; a.RH = p->R[1]; a.RW = p->R[2];
+  a.TD = p->T[0]; a.TH = p->T[1]; a.TW = p->T[2];
+  for (int d = 0; d < 3; ++d) { a.rs[d] = p->rstride[d]; a.tb[d] = p->tbase[d]; a.ts[d] = p->tstep[d]; a.os[d] = p->ostride[d]; a.oo[d] = p->ooffset[d]; }
+  a.xsn = X.sn; a.xsd = X.sd; a.xsh = X.sh; a.xsw = X.sw;
+  a.ysn = Y.sn; a.ysd = Y.sd; a.ysh = Y.sh; a.ysw = Y.sw;
+  a.cink = round_up(X.C, 64); a.cin_lanes = X.lanes;
+  a.cout = p->cout; a.cout_lanes = Y.lanes; a.wrows = round_up(p->cout, 16);
+  a.act = p->act; a.slope = p->slope;
+  a.M = (long)X.N * a.RD * a.RH * a.RW;
+  a.xbytes = (unsigned)(cl5_extent(X) * 2);
+  a.wbytes = (unsigned)((long)a.wrows * a.TD * a.TH * a.TW * a.cink * 2);
+  bool check = false;
+  const int I[3] = {X.D, X.H, X.W};
+  for (int d = 0; d < 3; ++d) {
+    const long lo0 = p->tbase[d], lo1 = p->tbase[d] + (long)p->tstep[d] * (p->T[d] - 1);
+    const long mn = lo0 < lo1 ? lo0 : lo1, mx = (lo0 < lo1 ? lo1 : lo0) + (long)(p->R[d] - 1) * p->rstride[d];
+    if (mn < 0 || mx >= I[d]) check = true;
+  }
+  const int nf = a.wrows / 16;
+  const int fn = ig4_fn(nf);
+  // rows per tile: 256 (FM = 4, two workgroups per CU, weight-fragment reads amortised over 4 row fragments: ~1000-1060
+  // TFLOP/s when the grid fills the chip) or 128 (FM = 2, three per CU, ~820-900).  Few-tile problems lose whole CUs to
+  // the coarser grid, so estimate both from the measured rates and the fill of the last round of workgroups
+  const int ntn = (nf + fn - 1) / fn;
+  const long b2 = ((a.M + 127) / 128) * ntn, b4 = ((a.M + 255) / 256) * ntn;
+  const double e2 = b2 <= 768 ? b2 / 768.0 : 0.5 + 0.5 * b2 / (double)((b2 + 767) / 768 * 768);  // co-resident workgroups speed up when a CU is not full
+  const double e4 = b4 <= 512 ? b4 / 512.0 : b4 / (double)((b4 + 511) / 512 * 512);
+  const char* e = getenv("RG_FM");
+  const int fm = e ? atoi(e) : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
+#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, st); else launch_igemm4<2, FN_>(a, check, st); } while (0)
+  switch (fn) {
+    case 4: RG_L4(4); break;
+    case 5: RG_L4(5); break;
+    case 8: RG_L4(8); break;
+    default: RG_L4(9); break;
+  }
+  return RG_OK;
+}
