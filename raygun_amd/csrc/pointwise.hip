@@ -72,37 +72,45 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
 }
 
 // ---------------------------------------------------------------------------- weight packing
-// Tiled through LDS so that BOTH sides move whole 128-byte runs: a workgroup takes T0 values of dim0 x T1 of dim1 x a chunk
-// of source taps.  swap 0 (reduced channel = dim1): 1 x 64 — one contiguous 64*kvol-float read, 64-channel packed rows.
-// swap 1 (reduced channel = dim0): 64 x 4 — 4*kvol-float reads per dim0 value, again 64-channel packed rows.
-#define PK_ELEMS 256
+// fp32 master weights (dim0, dim1, KD, KH, KW) -> bf16 [rows16][tap][redK] (rows = dim0, reduced channel = dim1; swap: the
+// other way round).  A workgroup takes PK_R packed rows x 64 reduced channels x a chunk of <= 32 SOURCE taps through LDS, so
+// that both sides move long runs: the read is PK_R (swap: 64) contiguous runs of 64*kvol (PK_R*kvol) floats, the write
+// one 16-byte store (8 reduced channels of one row and tap) per thread-iteration.  The tile grid covers the padded
+// buffer (rows up to rows16, channels up to redK), pad entries are written as zeros: no memset pass.
+#define PK_R 4
 #define PK_MAXTAPS 32
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
-  __shared__ float tile[PK_ELEMS][PK_MAXTAPS + 1];
-  const int T0 = p.swap ? 64 : 1, T1 = p.swap ? 4 : 64;
+  __shared__ float tile[PK_R * 64][PK_MAXTAPS + 1];  // [rr*64 + kk][source tap - t0]
   const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2];
   const int kvol = p.K[0] * p.K[1] * p.K[2];
-  const int n1 = (p.dim1 + T1 - 1) / T1;
-  const int d0b = (blockIdx.x / n1) * T0, d1b = (blockIdx.x % n1) * T1;
-  for (int t0 = 0; t0 < kvol; t0 += PK_MAXTAPS) {  // chunks of the SOURCE tap axis
+  const int nkt = (red32 + 63) / 64;
+  const int rb = (blockIdx.x / nkt) * PK_R, kb = (blockIdx.x % nkt) * 64;  // first packed row / reduced channel of the tile
+  const int ngrp = (red32 - kb < 64 ? red32 - kb : 64) / 8;                  // 8-channel groups to write (pads included)
+  for (int t0 = 0; t0 < kvol; t0 += PK_MAXTAPS) {
     const int nt = kvol - t0 < PK_MAXTAPS ? kvol - t0 : PK_MAXTAPS;
-    for (int i = threadIdx.x; i < T0 * T1 * nt; i += 256) {
-      const int t = i % nt, e = i / nt, d1 = e % T1, d0 = e / T1;
-      float v = 0.f;
-      if (d0b + d0 < p.dim0 && d1b + d1 < p.dim1) v = w[((long)(d0b + d0) * p.dim1 + d1b + d1) * kvol + t0 + t];
-      tile[e][t] = v;
+    // fill: lane = source tap (contiguous in memory), 8 (row, channel) pairs per pass; no per-element index divisions
+    {
+      const int t = threadIdx.x & 31, e0 = threadIdx.x >> 5;
+#pragma unroll 8
+      for (int e = e0; e < PK_R * 64; e += 8) {
+        const int rr = e >> 6, kk = e & 63;
+        const int row = rb + rr, k = kb + kk;
+        float v = 0.f;
+        if (t < nt && row < rows && k < red) v = p.swap ? w[((long)k * p.dim1 + row) * kvol + t0 + t] : w[((long)row * p.dim1 + k) * kvol + t0 + t];
+        tile[e][t] = v;
+      }
     }
     __syncthreads();
-    const int TR = p.swap ? T1 : T0, TK = p.swap ? T0 : T1;  // packed rows / reduced channels inside the tile
-    for (int i = threadIdx.x; i < TR * TK * ntap; i += 256) {
-      const int kk = i % TK, tap = (i / TK) % ntap, rr = i / (TK * ntap);
+    for (int i = threadIdx.x; i < PK_R * ntap * ngrp; i += 256) {
+      const int g = i % ngrp, tap = (i / ngrp) % ntap, rr = i / (ngrp * ntap);
       const int jw = tap % p.ntap[2], jh = (tap / p.ntap[2]) % p.ntap[1], jd = tap / (p.ntap[2] * p.ntap[1]);
       const int kd = p.k0[0] + p.kstep[0] * jd, kh = p.k0[1] + p.kstep[1] * jh, kw = p.k0[2] + p.kstep[2] * jw;
       const int kidx = (kd * p.K[1] + kh) * p.K[2] + kw;
-      if (kidx < t0 || kidx >= t0 + nt) continue;
-      const int d0 = p.swap ? kk : rr, d1 = p.swap ? rr : kk;
-      const int row = (p.swap ? d1b : d0b) + rr, k = (p.swap ? d0b : d1b) + kk;
-      if (row < rows && k < red) out[((long)row * ntap + tap) * red32 + k] = f2bf(tile[d0 * T1 + d1][kidx - t0]);
+      if (kidx < t0 || kidx >= t0 + nt || rb + rr >= rows16) continue;
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = (short)f2bf(tile[rr * 64 + g * 8 + q][kidx - t0]);
+      *(bf16x8*)(out + ((long)(rb + rr) * ntap + tap) * red32 + kb + g * 8) = o;
     }
     __syncthreads();
   }
@@ -127,10 +135,9 @@ extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_param
   if (!w || !packed || pack_dims(p, &rows, &red)) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: bad params");
   const int rows16 = round_up(rows, 16), red32 = round_up(red, pack_align(p));
   const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
-  // pad rows/lanes of the packed buffer are zero; the tiled kernel writes the real entries
-  if (hipMemsetAsync(packed, 0, (size_t)total * 2, (hipStream_t)s) != hipSuccess) RG_FAIL(RG_ERR_HIP, "pack_weights: memset failed");
-  const int pt0 = p->swap ? 64 : 1, pt1 = p->swap ? 4 : 64;
-  const int nblk = ((p->dim0 + pt0 - 1) / pt0) * ((p->dim1 + pt1 - 1) / pt1);
+  (void)total;
+  if (((uintptr_t)packed) & 15) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: packed buffer must be 16B aligned");
+  const int nblk = ((rows16 + PK_R - 1) / PK_R) * ((red32 + 63) / 64);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
   RG_CHECK_LAUNCH();
   return RG_OK;
@@ -453,17 +460,33 @@ extern "C" int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y
 }
 
 // ---------------------------------------------------------------------------- fused Adam (torch.optim.Adam, no amsgrad)
+__device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
+                                         float bc1, float bc2_sqrt, float gscale) {
+  gi *= gscale;
+  if (wd != 0.f) gi += wd * pi;
+  mi = b1 * mi + (1.f - b1) * gi;
+  vi = b2 * vi + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi = pi - (lr / bc1) * (mi / denom);
+}
+// 16 bytes per lane and stream (7 streams of 4 B/element: the step is pure HBM traffic); `vec` = all four pointers 16-B aligned
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2_sqrt, float gscale) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float gi = g[i] * gscale;
-    const float pi = p[i];
-    if (wd != 0.f) gi += wd * pi;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+                            float wd, float bc1, float bc2_sqrt, float gscale, int vec) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+  const long n4 = vec ? n / 4 : 0;
+  for (long i = tid; i < n4; i += nthr) {
+    float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+    const float4 gg = ((const float4*)g)[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adam_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adam_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adam_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+  }
+  for (long i = n4 * 4 + tid; i < n; i += nthr) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
 extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
@@ -471,8 +494,9 @@ extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_
   if (n == 0) return RG_OK;
   if (!p || !g || !m || !v || n < 0 || step < 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2), grad_scale);
+  const int vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2), grad_scale, vec);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
