@@ -294,7 +294,7 @@ int rg_launch_igemm3(const CL5& X, const CL5& Y, const void* w_packed, const flo
 bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
 bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p);
 int rg_igemm4_tile_n(int cout);
-int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st);
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
 static const void* zero_page() {
   static const void* cache[64] = {nullptr};
@@ -324,9 +324,14 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
     // igemm4 (activations straight into fragments) for 128/144-channel tiles; the kw-reuse kernel keeps the unpadded
     // 128-channel stride-1 layers (787 vs 731 TFLOP/s) and both LDS kernels the narrow tiles
     const bool i3 = rg_igemm3_ok(X, p);
-    if (rg_igemm4_ok(X, p) && !(i3 && rg_igemm4_tile_n(p->cout) == 8)) rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s);
+    if (rg_igemm4_ok(X, p) && !(i3 && rg_igemm4_tile_n(p->cout) == 8)) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0))) return rc; }
     else if (i3) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     else rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
+    RG_CHECK_LAUNCH();
+    return RG_OK;
+  }
+  if (rg_conv3d_kalign(X.C, p->cout) == 1) {  // K flattened across taps, activations straight into fragments
+    if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 1))) return rc;
     RG_CHECK_LAUNCH();
     return RG_OK;
   }

@@ -36,6 +36,7 @@ struct Igemm4Args {
   long M;
   int tiles_m, tiles_n;
   unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
+  int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
 };
 
 typedef __attribute__((address_space(3))) void* lptr4_t;
@@ -46,12 +47,17 @@ template <int N>
 __device__ __forceinline__ void ld4_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 #define IG4_OOB 0x80000000u
 
-template <int FM, int FN, bool CHECK>
+// FLAT: K is walked in 8-lane pieces ACROSS taps (K = taps*lanes padded once to 64, not per tap): channel counts that are
+// not multiples of 64 (12, 72, 84 ... lanes) waste no MFMA work.  A 64-wide K-step then mixes taps, so each lane looks its
+// two pieces (k-half 0 and 1) up in an LDS table {byte offset of (tap, lane group), packed tap displacement}.
+struct PieceInfo { int off; int disp; };  // disp < 0: piece past the end of K
+template <int FM, int FN, bool CHECK, bool FLAT>
 __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Args a) {
   constexpr int BM = 64 * FM, BN = FN * 16;
   constexpr int BPIECES = ((BN / 8) + 3) / 4 * 4, BROWS = BPIECES * 8, BPW = BPIECES / 4;
   constexpr int BSTAGE = BROWS * 64;  // bf16 elements per weight stage
   __shared__ __attribute__((aligned(128))) bf16_t lds[2 * BSTAGE];
+  extern __shared__ PieceInfo ptab[];  // FLAT only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwg = a.tiles_m * a.tiles_n;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
     const int rd = (int)(t % a.RD); t /= a.RD;
     rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
     // tap offsets are added later and may be negative: keep the sum inside [0, 2^31) for valid lanes, park invalid rows
-    rbase[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + fg * 8) * 2) : IG4_OOB;
+    rbase[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + (FLAT ? 0 : fg * 8)) * 2) : IG4_OOB;
     if (!v) { rd0[i] = rh0[i] = rw0[i] = -(1 << 20); }
   }
   // ---- the BPW weight pieces of this lane: per-thread constant byte offset (row, swizzled slot); the tap/chunk part is
@@ -87,10 +93,24 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
     const int piece = wave * BPW + i, row = piece * 8 + lrow, n = n0 + row;
     const bool v = row < BN && n < a.wrows;
     const int slot = lslot ^ ((piece & 1) * 4 + (lrow >> 1));
-    wv[i] = v ? (unsigned)(((long)n * ntaps * a.cink + slot * 8) * 2) : IG4_OOB;
+    wv[i] = v ? (unsigned)(((long)n * (FLAT ? a.krow : ntaps * a.cink) + slot * 8) * 2) : IG4_OOB;
   }
   const int nchunk = a.cink >> 6;
-  const int nk = ntaps * nchunk;
+  const int nk = FLAT ? a.krow >> 6 : ntaps * nchunk;
+  if (FLAT) {
+    for (int P = tid; P < nk * 8; P += 256) {
+      const int tap = P / a.cp, c8 = P - tap * a.cp;
+      PieceInfo e; e.off = 0; e.disp = -1;
+      if (tap < ntaps) {
+        const int kw_ = tap % a.TW, kh_ = (tap / a.TW) % a.TH, kd_ = tap / (a.TW * a.TH);
+        const int od = kd_ * a.ts[0], oh = kh_ * a.ts[1], ow = kw_ * a.ts[2];
+        e.off = ((int)(od * a.xsd + oh * a.xsh + ow * a.xsw) + c8 * 8) * 2;
+        e.disp = (od + 512) | ((oh + 512) << 10) | ((ow + 512) << 20);
+      }
+      ptab[P] = e;
+    }
+    __syncthreads();
+  }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.xbytes, 0x00020000);
   const auto rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.wbytes, 0x00020000);
 
@@ -98,6 +118,7 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
   // two steps ahead (registers, then LDS), the activation fragments one (registers only)
   int pchunk = 0, kd = 0, kh = 0, kw = 0;  // activations
   int btap = 0, bchunk = 0;                // weights
+  int astep = 0, bstep = 0;                // FLAT: plain K-step counters
   auto advance_a = [&]() {
     ++kw;
     const int cw = kw == a.TW; kw = cw ? 0 : kw; kh += cw;
@@ -107,11 +128,11 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
   auto advance_b = [&]() { ++btap; const int c = btap == ntaps; btap = c ? 0 : btap; bchunk += c; };
   u32x4_t sb[BPW];  // one stage of weights in flight through the registers
   auto load_b = [&]() {
-    const bool ok = bchunk < nchunk;
-    const int so = ok ? (btap * a.cink + bchunk * 64) * 2 : 0;
+    const bool ok = FLAT ? bstep < nk : bchunk < nchunk;
+    const int so = ok ? (FLAT ? bstep * 128 : (btap * a.cink + bchunk * 64) * 2) : 0;
 #pragma unroll
     for (int i = 0; i < BPW; ++i) sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw_, (int)(ok ? wv[i] : IG4_OOB), so, 0);
-    advance_b();
+    if (FLAT) ++bstep; else advance_b();
   };
   // activation fragments live in ONE register set: the k-half 0 pieces of step ks+1 are loaded once the k-half 0
   // MFMAs of step ks have issued (mid-step), the k-half 1 pieces at the end of the step — half a step of latency cover
@@ -119,6 +140,24 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
   u32x4_t xa[FM][2];
   unsigned vo0[FM], vo1[FM];
   auto prep_a = [&]() {
+    if constexpr (FLAT) {
+      PieceInfo e0, e1;
+      e0.off = 0; e0.disp = -1; e1 = e0;
+      if (astep < nk) { e0 = ptab[astep * 8 + fg]; e1 = ptab[astep * 8 + 4 + fg]; }
+      ++astep;
+      const int d0 = (e0.disp & 1023) - 512, h0 = ((e0.disp >> 10) & 1023) - 512, w0 = ((e0.disp >> 20) & 1023) - 512;
+      const int d1 = (e1.disp & 1023) - 512, h1 = ((e1.disp >> 10) & 1023) - 512, w1 = ((e1.disp >> 20) & 1023) - 512;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bool ok0 = e0.disp >= 0, ok1 = e1.disp >= 0;
+        if (CHECK) {
+          ok0 &= ((unsigned)(rd0[i] + d0) < (unsigned)a.ID) & ((unsigned)(rh0[i] + h0) < (unsigned)a.IH) & ((unsigned)(rw0[i] + w0) < (unsigned)a.IW);
+          ok1 &= ((unsigned)(rd0[i] + d1) < (unsigned)a.ID) & ((unsigned)(rh0[i] + h1) < (unsigned)a.IH) & ((unsigned)(rw0[i] + w1) < (unsigned)a.IW);
+        }
+        vo0[i] = ok0 ? rbase[i] + (unsigned)e0.off : IG4_OOB;
+        vo1[i] = ok1 ? rbase[i] + (unsigned)e1.off : IG4_OOB;
+      }
+    } else {
     const int od = kd * a.ts[0], oh = kh * a.ts[1], ow = kw * a.ts[2];
     const int tapoff = ((int)(od * a.xsd + oh * a.xsh + ow * a.xsw) + pchunk * 64) * 2;
     const int c = pchunk * 64 + fg * 8;
@@ -132,6 +171,7 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
       vo1[i] = (ok & c1) ? vo + 64u : IG4_OOB;
     }
     advance_a();
+    }
   };
   auto load_a0 = [&]() {
 #pragma unroll
@@ -172,7 +212,7 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
     const unsigned b0 = b_lane + stage * (BSTAGE * 2), b1 = b0 ^ 64u;
     bf16x8 wf[3];
     ld4_16<0>(wf[0], b0);
-    ld4_16<2048>(wf[1], b0);
+    ld4_16<(1 % FN) * 2048>(wf[1], (1 / FN) ? b1 : b0);
     s4for<T2>([&](auto T) {
       constexpr int t = decltype(T)::value;
       constexpr int kk = t / FN, j = t % FN;
@@ -225,13 +265,22 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
 }
 
 template <int FM, int FN>
-static void launch_igemm4(Igemm4Args& a, bool check, hipStream_t s) {
+static void launch_igemm4(Igemm4Args& a, bool check, bool flat, hipStream_t s) {
   constexpr int BM = 64 * FM, BN = FN * 16;
   a.tiles_m = (int)((a.M + BM - 1) / BM);
   a.tiles_n = (a.cout_lanes + BN - 1) / BN;
-  rg_set_kernel_name("igemm4_kernel<%d,%d,%d>", FM, FN, (int)check);
-  if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm4_kernel<FM, FN, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+  rg_set_kernel_name("igemm4_kernel<%d,%d,%d%s>", FM, FN, (int)check, flat ? ",flat" : "");
+  const dim3 grid(a.tiles_m * a.tiles_n);
+  if (flat) {
+    const size_t shm = (size_t)(a.krow / 8) * sizeof(PieceInfo);
+    if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true, true>), grid, dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((igemm4_kernel<FM, FN, false, true>), grid, dim3(256), shm, s, a);
+  } else {
+    if constexpr (FN >= 4) {
+      if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true, false>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((igemm4_kernel<FM, FN, false, false>), grid, dim3(256), 0, s, a);
+    }
+  }
 }
 
 // extent in elements of a channels-last view (last addressable lane + 1)
@@ -256,7 +305,7 @@ bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p) {
 }
 int rg_igemm4_tile_n(int cout) { return ig4_fn(round_up(cout, 16) / 16); }
 
-int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st) {
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat) {
   Igemm4Args a;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
@@ -269,17 +318,26 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   a.cout = p->cout; a.cout_lanes = Y.lanes; a.wrows = round_up(p->cout, 16);
   a.act = p->act; a.slope = p->slope;
   a.M = (long)X.N * a.RD * a.RH * a.RW;
+  const int ntaps = a.TD * a.TH * a.TW;
+  a.cp = X.lanes / 8;
+  a.krow = round_up(ntaps * X.lanes, 64);
+  const long wel = (long)a.wrows * (flat ? a.krow : ntaps * a.cink);
+  if (cl5_extent(X) * 2 >= (1L << 30) || wel * 2 >= (1L << 30))
+    RG_FAIL(RG_ERR_UNSUPPORTED, "conv: input view or packed weights of 1 GiB or more are not supported by the fragment-direct kernel");
   a.xbytes = (unsigned)(cl5_extent(X) * 2);
-  a.wbytes = (unsigned)((long)a.wrows * a.TD * a.TH * a.TW * a.cink * 2);
+  a.wbytes = (unsigned)(wel * 2);
   bool check = false;
   const int I[3] = {X.D, X.H, X.W};
   for (int d = 0; d < 3; ++d) {
     const long lo0 = p->tbase[d], lo1 = p->tbase[d] + (long)p->tstep[d] * (p->T[d] - 1);
     const long mn = lo0 < lo1 ? lo0 : lo1, mx = (lo0 < lo1 ? lo1 : lo0) + (long)(p->R[d] - 1) * p->rstride[d];
     if (mn < 0 || mx >= I[d]) check = true;
+    if (flat && (long)(p->T[d] - 1) * (p->tstep[d] < 0 ? -p->tstep[d] : p->tstep[d]) > 511)
+      RG_FAIL(RG_ERR_UNSUPPORTED, "conv: tap displacement beyond 511 voxels along dim %d", d);
   }
+  if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   const int nf = a.wrows / 16;
-  const int fn = ig4_fn(nf);
+  const int fn = flat ? (nf <= 6 ? nf : (nf == 7 ? 8 : ig4_fn(nf))) : ig4_fn(nf);
   // rows per tile: 256 (FM = 4, two workgroups per CU, weight-fragment reads amortised over 4 row fragments: ~1000-1060
   // TFLOP/s when the grid fills the chip) or 128 (FM = 2, three per CU, ~820-900).  Few-tile problems lose whole CUs to
   // the coarser grid, so estimate both from the measured rates and the fill of the last round of workgroups
@@ -289,10 +347,14 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   const double e4 = b4 <= 512 ? b4 / 512.0 : b4 / (double)((b4 + 511) / 512 * 512);
   const char* e = getenv("RG_FM");
   const int fm = e ? atoi(e) : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
-#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, st); else launch_igemm4<2, FN_>(a, check, st); } while (0)
+#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else launch_igemm4<2, FN_>(a, check, flat != 0, st); } while (0)
   switch (fn) {
+    case 1: RG_L4(1); break;
+    case 2: RG_L4(2); break;
+    case 3: RG_L4(3); break;
     case 4: RG_L4(4); break;
     case 5: RG_L4(5); break;
+    case 6: RG_L4(6); break;
     case 8: RG_L4(8); break;
     default: RG_L4(9); break;
   }

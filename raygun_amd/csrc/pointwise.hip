@@ -79,13 +79,20 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
 // buffer (rows up to rows16, channels up to redK), pad entries are written as zeros: no memset pass.
 #define PK_R 4
 #define PK_MAXTAPS 32
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32, long rowlen) {
   __shared__ float tile[PK_R * 64][PK_MAXTAPS + 1];  // [rr*64 + kk][source tap - t0]
   const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2];
   const int kvol = p.K[0] * p.K[1] * p.K[2];
   const int nkt = (red32 + 63) / 64;
   const int rb = (blockIdx.x / nkt) * PK_R, kb = (blockIdx.x % nkt) * 64;  // first packed row / reduced channel of the tile
   const int ngrp = (red32 - kb < 64 ? red32 - kb : 64) / 8;                  // 8-channel groups to write (pads included)
+  if (kb == 0) {  // flat rows (red_align 1) are padded once, after the last tap: zero that tail
+    const int tail = (int)(rowlen - (long)ntap * red32) / 8;
+    for (int i = threadIdx.x; i < PK_R * tail; i += 256) {
+      const int rr = i / tail, g = i - rr * tail;
+      if (rb + rr < rows16) *(bf16x8*)(out + (long)(rb + rr) * rowlen + (long)ntap * red32 + g * 8) = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
   for (int t0 = 0; t0 < kvol; t0 += PK_MAXTAPS) {
     const int nt = kvol - t0 < PK_MAXTAPS ? kvol - t0 : PK_MAXTAPS;
     // fill: lane = source tap (contiguous in memory), 8 (row, channel) pairs per pass; no per-element index divisions
@@ -110,14 +117,18 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_
       bf16x8 o;
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] = (short)f2bf(tile[rr * 64 + g * 8 + q][kidx - t0]);
-      *(bf16x8*)(out + ((long)(rb + rr) * ntap + tap) * red32 + kb + g * 8) = o;
+      *(bf16x8*)(out + (long)(rb + rr) * rowlen + (long)tap * red32 + kb + g * 8) = o;
     }
     __syncthreads();
   }
 }
-static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : (p->red_align == 8 ? 8 : 32); }
+static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : ((p->red_align == 8 || p->red_align == 1) ? 8 : 32); }
+static long pack_rowlen(const rg_pack_params* p, int red) {
+  const long n = (long)p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, pack_align(p));
+  return p->red_align == 1 ? (n + 63) / 64 * 64 : n;
+}
 static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
-  if (!p || p->dim0 <= 0 || p->dim1 <= 0 || (p->red_align != 0 && p->red_align != 8 && p->red_align != 32 && p->red_align != 64)) return -1;
+  if (!p || p->dim0 <= 0 || p->dim1 <= 0 || (p->red_align != 0 && p->red_align != 1 && p->red_align != 8 && p->red_align != 32 && p->red_align != 64)) return -1;
   for (int d = 0; d < 3; ++d) {
     if (p->K[d] <= 0 || p->ntap[d] <= 0 || p->k0[d] < 0 || p->kstep[d] <= 0) return -1;
     if (p->k0[d] + p->kstep[d] * (p->ntap[d] - 1) >= p->K[d]) return -1;
@@ -128,17 +139,17 @@ static int pack_dims(const rg_pack_params* p, int* rows, int* red) {
 extern "C" int64_t rg_pack_weights_bytes(const rg_pack_params* p) {
   int rows, red;
   if (pack_dims(p, &rows, &red)) return -1;
-  return (int64_t)round_up(rows, 16) * p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, pack_align(p)) * 2;
+  return (int64_t)round_up(rows, 16) * pack_rowlen(p, red) * 2;
 }
 extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_params* p, rg_stream s) {
   int rows, red;
   if (!w || !packed || pack_dims(p, &rows, &red)) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: bad params");
   const int rows16 = round_up(rows, 16), red32 = round_up(red, pack_align(p));
-  const long total = (long)rows16 * p->ntap[0] * p->ntap[1] * p->ntap[2] * red32;
+  const long total = (long)rows16 * pack_rowlen(p, red);
   (void)total;
   if (((uintptr_t)packed) & 15) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: packed buffer must be 16B aligned");
   const int nblk = ((rows16 + PK_R - 1) / PK_R) * ((red32 + 63) / 64);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32, pack_rowlen(p, red));
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

@@ -86,6 +86,14 @@ CONV_CASES = [
     (144, 144, 3, 1, 0, (4, 19, 19), "relu"),
     (64, 64, 7, 1, 0, (8, 30, 30), "none"),
     (80, 72, 3, 1, 0, (5, 23, 37), "none"),
+    # CycleGAN generator stem/tail and PatchGAN layers (networks/ResNet.py:283-345, NLayerDiscriminator.py): folded
+    # single-channel stems, one-channel tails of wide inputs, strided 4^3 convs
+    (1, 64, 4, 2, 1, (12, 12, 12), "leaky"),
+    (1, 32, 7, 1, 0, (10, 11, 12), "relu"),
+    (64, 1, 7, 1, 0, (9, 9, 10), "tanh"),
+    (256, 1, 4, 1, 1, (5, 6, 6), "none"),
+    (72, 1, 3, 1, 1, (5, 6, 7), "none"),
+    (24, 40, 3, 1, 1, (6, 6, 7), "relu"),
 ]
 
 
@@ -97,7 +105,7 @@ def test_conv3d(cin, cout, k, s, p, sp, act):
     w = rnd((cout, cin) + kk, 2) * (1.0 / np.sqrt(cin * np.prod(kk)))
     w = bf(w)
     b = rnd((cout,), 3)
-    afn = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.2), "sigmoid": torch.sigmoid}[act]
+    afn = {"none": lambda t: t, "relu": F.relu, "leaky": lambda t: F.leaky_relu(t, 0.2), "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act]
     errs = run_pair(lambda x_, w_, b_: ops.conv3d(x_, w_, b_, s, p, act, 0.2),
                     lambda x_, w_, b_: afn(F.conv3d(x_, w_, b_, s, p)), [x], [w, b])
     check(errs)
