@@ -24,6 +24,8 @@ struct WgradArgs {
   long M; long rows_per_split; int nsplit;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define WG_OOB 0x80000000u  // voffset of a piece that loads nothing: stays >= num_records (< 2^30) after any per-step add
 struct RowInfo { long goff; long xoff; };  // -1 = row contributes zeros
 
 constexpr int wg_pad(int t) { return ((t / 16) & 1) ? t : t + 16; }
@@ -318,14 +320,19 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
 // (10.8 KB instead of 28.7 KB for 3x3x3), and ds_read_b64_tr_b16 still sees 4 consecutive k-rows per block.
 #define WL_MAXJ 9    /* (kd,kh) pairs per workgroup */
 #define WL_MAXW 8    /* taps along W */
-struct WgradLineArgs { WgradArgs w; long units; long units_per_split; int wchunks; };
+// Same load-path recipe as wgrad_kw_kernel: every 16-byte piece has a per-thread constant byte offset relative to a
+// wave-uniform base, buffer descriptors do the bounds checks (G: one output line, rows past RW read zero; X: the whole
+// tensor), the unit cursor is incremental, and the loads of unit u+1 fly during the MFMAs of unit u (LDS double buffer,
+// one barrier per unit).  CHECK (zero-padded convolutions) adds the per-piece (d,h,w) range test.
+struct WgradLineArgs { WgradArgs w; long units; long units_per_split; int wchunks; unsigned xbytes; };
+// TWM = taps along W the instantiation is sized for (LDS rows per line, accumulators per wave): 3 or WL_MAXW
+template <bool CHECK, int TWM>
 __global__ __launch_bounds__(256) void wgrad_line_kernel(WgradLineArgs p) {
   const WgradArgs& a = p.w;
-  constexpr int XR = 32 + WL_MAXW - 1;
-  __shared__ __attribute__((aligned(16))) bf16_t lds[(32 + WL_MAXJ * XR) * 16];
-  bf16_t* Gs = lds;
-  bf16_t* Xs = lds + 32 * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int XR = 32 + TWM - 1;
+  constexpr int STAGE = (32 + WL_MAXJ * XR) * 16;  // bf16 elements per LDS stage
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntaps = a.TD * a.TH * a.TW;
   const int TDH = a.TD * a.TH;
   const int j0 = blockIdx.x * WL_MAXJ;
@@ -333,77 +340,100 @@ __global__ __launch_bounds__(256) void wgrad_line_kernel(WgradLineArgs p) {
   const int xrows = 32 + a.TW - 1;
   const long ubeg = (long)blockIdx.z * p.units_per_split;
   long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
-  constexpr int NACC = (WL_MAXJ * WL_MAXW + 3) / 4;
+  constexpr int NACC = (WL_MAXJ * TWM + 3) / 4;
   f32x4 acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
   typedef __attribute__((address_space(3))) bf16x4 lds_b64;
   const int nloc = nj * a.TW;  // taps of this workgroup: local index t = jj*TW + kw
-  // per-thread load list, fixed for the whole kernel: code = jj<<10 | row<<4 | half*8 (jj == 15: the G tile), -1 = none
+  const int gsw2 = (int)a.gsw * 2, xsw2 = (int)a.xsw * 2;
+  // per-thread piece list, fixed for the whole kernel.  Piece q < 64: the G tile (row q>>1, half q&1); then the X tiles.
   constexpr int NLD = (64 + WL_MAXJ * XR * 2 + 255) / 256;
-  int lc[NLD], lkh[NLD], lkd[NLD];
+  unsigned pv[NLD]; int pl[NLD]; int pd[NLD], ph[NLD], pw[NLD];
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
     const int q = tid + 256 * k;
-    lc[k] = -1; lkh[k] = lkd[k] = 0;
-    if (q < 64) lc[k] = (15 << 10) | ((q >> 1) << 4) | ((q & 1) * 8);
-    else if (q < 64 + nj * xrows * 2) {
-      const int q2 = q - 64, rr = (q2 >> 1) % xrows, jj = (q2 >> 1) / xrows;
-      lc[k] = (jj << 10) | (rr << 4) | ((q2 & 1) * 8);
-      lkh[k] = (j0 + jj) % a.TH; lkd[k] = (j0 + jj) / a.TH;
+    pv[k] = WG_OOB; pl[k] = -1; pd[k] = ph[k] = pw[k] = 0;
+    if (q < 64) {
+      const int rr = q >> 1, cc = (q & 1) * 8;
+      pl[k] = rr * 16 + cc;
+      if (cc < a.alanes) pv[k] = (unsigned)(rr * gsw2 + cc * 2);
+    } else if (q < 64 + nj * xrows * 2) {
+      const int q2 = q - 64, cc = (q2 & 1) * 8, rr = (q2 >> 1) % xrows, jj = (q2 >> 1) / xrows;
+      const int kh = (j0 + jj) % a.TH, kd = (j0 + jj) / a.TH;
+      pl[k] = (32 + jj * XR + rr) * 16 + cc;
+      pd[k] = kd; ph[k] = kh; pw[k] = rr;
+      if (cc < a.blanes) pv[k] = (unsigned)((int)(kd * a.xsd + kh * a.xsh) * 2 + rr * xsw2 + cc * 2);
     }
   }
-  for (long u = ubeg; u < uend; ++u) {
-    unsigned t = (unsigned)u;  // units < 2^31 (host-checked): 32-bit divisions only
-    const int wc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
-    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
-    const int rd = (int)(t % (unsigned)a.RD); const long n = t / (unsigned)a.RD;
-    const int w0 = wc * 32;
-    __syncthreads();  // previous step's fragment reads are done
-    // G tile: 32 rows x 2 halves; X tiles: nj x xrows x 2 halves
-    const long gline = n * a.gsn + rd * a.gsd + rh * a.gsh;
-    const long xline = n * a.xsn;
-    bf16x8 v[NLD];
+  const bool isg0 = tid < 64;  // only piece 0 of the first 64 threads belongs to the G tile
+  int xfo[NACC];               // LDS element offset of tap (wave + 4 i)'s fragment rows inside a stage, -1: no such tap
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {  // all loads first, then all LDS stores
-      v[k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      const int cc = lc[k] & 8, rr = (lc[k] >> 4) & 63, jj = lc[k] >> 10;
-      if (lc[k] < 0) continue;
-      if (jj == 15) {
-        if (w0 + rr < a.RW && cc < a.alanes) v[k] = *(const bf16x8*)(a.g + gline + (long)(w0 + rr) * a.gsw + cc);
-      } else {
-        const int j = j0 + jj, kh = lkh[k], kd = lkd[k];
-        (void)j;
-        const int id = rd + a.tb[0] + kd, ih = rh + a.tb[1] + kh, iw = w0 + a.tb[2] + rr;
-        if (cc < a.blanes && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
-          v[k] = *(const bf16x8*)(a.x + xline + (long)id * a.xsd + (long)ih * a.xsh + (long)iw * a.xsw + cc);
-      }
-    }
+  for (int i = 0; i < NACC; ++i) {
+    const int tl = wave + 4 * i;
+    xfo[i] = tl < nloc ? (32 + (tl / a.TW) * XR + tl % a.TW + 8 * fg + fq) * 16 + 4 * fp : -1;
+  }
+  int cwc, crh, crd, cn;
+  {
+    unsigned t = (unsigned)ubeg;
+    cwc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+    crh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    crd = (int)(t % (unsigned)a.RD); cn = (int)(t / (unsigned)a.RD);
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)p.xbytes, 0x00020000);
+  u32x4 regs[NLD];
+  auto gload = [&]() {  // loads the unit under the cursor, then advances the cursor
+    const int w0 = cwc * 32;
+    const bf16_t* gbase = a.g + cn * a.gsn + crd * a.gsd + crh * a.gsh;
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, (short)0, a.RW * gsw2, 0x00020000);
+    const int id0 = crd + a.tb[0], ih0 = crh + a.tb[1], iw0 = w0 + a.tb[2];
+    const int xadd = (int)(cn * a.xsn + (long)id0 * a.xsd + (long)ih0 * a.xsh + (long)iw0 * a.xsw) * 2;  // may be negative (padding)
+    const int gadd = w0 * gsw2;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      if (lc[k] < 0) continue;
-      const int cc = lc[k] & 8, rr = (lc[k] >> 4) & 63, jj = lc[k] >> 10;
-      if (jj == 15) *(bf16x8*)(Gs + rr * 16 + cc) = v[k];
-      else *(bf16x8*)(Xs + (jj * XR + rr) * 16 + cc) = v[k];
+      if (k == 0) {
+        const u32x4 vg = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(pv[0] + (unsigned)gadd), 0, 0);
+        unsigned vo = pv[0] + (unsigned)xadd;
+        if (CHECK) vo = ((unsigned)(id0 + pd[0]) < (unsigned)a.ID && (unsigned)(ih0 + ph[0]) < (unsigned)a.IH && (unsigned)(iw0 + pw[0]) < (unsigned)a.IW) ? vo : WG_OOB;
+        const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(isg0 ? WG_OOB : vo), 0, 0);
+        regs[0] = isg0 ? vg : vx;
+      } else {
+        unsigned vo = pv[k] + (unsigned)xadd;
+        if (CHECK) vo = ((unsigned)(id0 + pd[k]) < (unsigned)a.ID && (unsigned)(ih0 + ph[k]) < (unsigned)a.IH && (unsigned)(iw0 + pw[k]) < (unsigned)a.IW) ? vo : WG_OOB;
+        regs[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo, 0, 0);
+      }
     }
-    __syncthreads();
+    if (++cwc == p.wchunks) { cwc = 0; if (++crh == a.RH) { crh = 0; if (++crd == a.RD) { crd = 0; ++cn; } } }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) if (pl[k] >= 0) *(u32x4*)(lds + buf * STAGE + pl[k]) = regs[k];
+  };
+  auto compute = [&](int buf) {
+    const bf16_t* Gs = lds + buf * STAGE;
     const bf16_t* gb = Gs + (8 * fg + fq) * 16 + 4 * fp;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb + 4 * 16));
     const bf16x8 gf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      const int tl = wave + 4 * i;
-      if (tl < nloc) {
-        const int jj = tl / a.TW, kw = tl % a.TW;
-        const bf16_t* xb = Xs + (jj * XR + kw + 8 * fg + fq) * 16 + 4 * fp;
+      if (wave + 4 * i < nloc) {
+        const bf16_t* xb = Gs + xfo[i];
         bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
         bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
         const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[i], 0, 0, 0);
       }
     }
+  };
+  if (ubeg < uend) gload();
+  int buf = 0;
+  for (long u = ubeg; u < uend; ++u, buf ^= 1) {
+    lstore(buf);
+    __syncthreads();
+    if (u + 1 < uend) gload();
+    compute(buf);
   }
   float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
   const int bb = lane & 15;
@@ -419,8 +449,12 @@ __global__ __launch_bounds__(256) void wgrad_line_kernel(WgradLineArgs p) {
     }
   }
 }
-static bool wgrad_line_ok(const rg_conv_params* p, int fa, int fb) {
+static long wg_extent(const CL5& T) {
+  return (long)(T.N - 1) * T.sn + (long)(T.D - 1) * T.sd + (long)(T.H - 1) * T.sh + (long)(T.W - 1) * T.sw + T.lanes;
+}
+static bool wgrad_line_ok(const CL5& G, const CL5& X, const rg_conv_params* p, int fa, int fb) {
   if (fa != 1 || fb != 1) return false;
+  if (wg_extent(X) * 2 >= (1L << 30) || wg_extent(G) * 2 >= (1L << 30)) return false;  // 32-bit byte offsets
   for (int d = 0; d < 3; ++d) if (p->rstride[d] != 1 || p->tstep[d] != 1) return false;
   return p->T[2] <= WL_MAXW;
 }
@@ -443,8 +477,6 @@ static bool wgrad_line_ok(const rg_conv_params* p, int fa, int fb) {
 // per-thread constant, the per-step part is wave-uniform (SGPR base in a buffer descriptor whose num_records does the
 // bounds check: out-of-range rows read as zero), and the unit -> (n, d, h, chunk) decode is incremental.
 struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; int flat; unsigned pmagic; int exp; };
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define WG_OOB 0x80000000u  // voffset of a piece that loads nothing: stays >= num_records (< 2^30) after any per-step add
 
 template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP>
 __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
@@ -685,7 +717,7 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
     *rows_per_split = ups;
     return;
   }
-  if (wgrad_line_ok(p, *fa, *fb)) {  // wgrad_line_kernel: split over (line, 32-voxel chunk) units
+  if (wgrad_line_ok(G, X, p, *fa, *fb)) {  // wgrad_line_kernel: split over (line, 32-voxel chunk) units
     const long wch = (p->R[2] + 31) / 32;
     const long units = (long)G.N * p->R[0] * p->R[1] * wch;
     const long groups = (p->T[0] * p->T[1] + WL_MAXJ - 1) / WL_MAXJ;
@@ -785,13 +817,24 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
     else if (kind == 8) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 9) hipLaunchKernelGGL((wgrad_kw_kernel<8, 4, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
     else hipLaunchKernelGGL((wgrad_kw_kernel<4, 8, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
-  } else if (wgrad_line_ok(p, fa, fb)) {
+  } else if (wgrad_line_ok(G, X, p, fa, fb)) {
     WgradLineArgs la; la.w = a;
     la.wchunks = (a.RW + 31) / 32;
     la.units = (long)G.N * a.RD * a.RH * la.wchunks;
     la.units_per_split = rps;
-    rg_set_kernel_name("wgrad_line_kernel");
-    hipLaunchKernelGGL(wgrad_line_kernel, dim3((a.TD * a.TH + WL_MAXJ - 1) / WL_MAXJ, 1, ns), dim3(256), 0, st, la);
+    la.xbytes = (unsigned)(wg_extent(X) * 2);
+    bool check = false;
+    const int I[3] = {X.D, X.H, X.W};
+    for (int d = 0; d < 3; ++d) if (p->tbase[d] < 0 || p->tbase[d] + p->T[d] - 1 + p->R[d] - 1 >= I[d]) check = true;
+    rg_set_kernel_name("wgrad_line_kernel<%d>", (int)check);
+    const dim3 grid((a.TD * a.TH + WL_MAXJ - 1) / WL_MAXJ, 1, ns);
+    if (a.TW <= 3) {
+      if (check) hipLaunchKernelGGL((wgrad_line_kernel<true, 3>), grid, dim3(256), 0, st, la);
+      else hipLaunchKernelGGL((wgrad_line_kernel<false, 3>), grid, dim3(256), 0, st, la);
+    } else {
+      if (check) hipLaunchKernelGGL((wgrad_line_kernel<true, WL_MAXW>), grid, dim3(256), 0, st, la);
+      else hipLaunchKernelGGL((wgrad_line_kernel<false, WL_MAXW>), grid, dim3(256), 0, st, la);
+    }
   } else if (fa == 1 && fb == 1) {
     rg_set_kernel_name("wgrad_thin_kernel");
     hipLaunchKernelGGL(wgrad_thin_kernel, dim3((ntaps + WT_TMAX - 1) / WT_TMAX, 1, ns), dim3(256), 0, st, a);
