@@ -305,6 +305,8 @@ bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p) {
 }
 int rg_igemm4_tile_n(int cout) { return ig4_fn(round_up(cout, 16) / 16); }
 
+bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
+int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat) {
   Igemm4Args a;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
@@ -336,6 +338,7 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
       RG_FAIL(RG_ERR_UNSUPPORTED, "conv: tap displacement beyond 511 voxels along dim %d", d);
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
+  if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !getenv("RG_NO_THIN")) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;
   const int fn = flat ? (nf <= 6 ? nf : (nf == 7 ? 8 : ig4_fn(nf))) : ig4_fn(nf);
   // rows per tile: 256 (FM = 4, two workgroups per CU, weight-fragment reads amortised over 4 row fragments: ~1000-1060
@@ -358,5 +361,150 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
     case 8: RG_L4(8); break;
     default: RG_L4(9); break;
   }
+  return RG_OK;
+}
+
+// ---- thin outputs (Cout <= 16): weights resident in LDS ----------------------------------------------------------------
+// A 16-channel output tile cannot amortise a per-K-step weight hand-over (8 MFMAs per barrier in igemm4<4,1>): these layers
+// are bound by the activation reads (one 1-KiB fragment load per MFMA), so everything else is taken off the loop.  The
+// whole packed weight matrix (16 rows x K, FLAT packing, <= 128 KB) is staged into LDS ONCE per workgroup, in 64-wide K
+// chunks with the fragment-read swizzle; workgroups are persistent over row tiles; the K loop has no barrier — per step
+// and lane two piece-table look-ups, 2*FM fragment loads (one step ahead, second register set), two ds_read_b128 and
+// 2*FM MFMAs.
+template <int FM, bool CHECK>
+__global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+  const int nk = a.krow >> 6;
+  bf16_t* wl = (bf16_t*)smem;                                  // [nk][16][64] swizzled
+  PieceInfo* ptab = (PieceInfo*)(smem + (size_t)nk * 2048);    // [nk*8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntaps = a.TD * a.TH * a.TW;
+  const int fr = lane & 15, fg = lane >> 4;
+  // stage the weights: 16-byte piece q = (row, k-piece); LDS slot = kslot ^ (row >> 1)
+  for (int q = tid; q < 16 * (a.krow >> 3); q += 256) {
+    const int row = q / (a.krow >> 3), kp = q - row * (a.krow >> 3);
+    const u32x4_t v = *(const u32x4_t*)(a.w + (long)row * a.krow + kp * 8);
+    *(u32x4_t*)(wl + (kp >> 3) * 1024 + row * 64 + (((kp & 7) ^ (row >> 1)) << 3)) = v;
+  }
+  for (int P = tid; P < nk * 8; P += 256) {
+    const int tap = P / a.cp, c8 = P - tap * a.cp;
+    PieceInfo e; e.off = 0; e.disp = -1;
+    if (tap < ntaps) {
+      const int kw_ = tap % a.TW, kh_ = (tap / a.TW) % a.TH, kd_ = tap / (a.TW * a.TH);
+      const int od = kd_ * a.ts[0], oh = kh_ * a.ts[1], ow = kw_ * a.ts[2];
+      e.off = ((int)(od * a.xsd + oh * a.xsh + ow * a.xsw) + c8 * 8) * 2;
+      e.disp = (od + 512) | ((oh + 512) << 10) | ((ow + 512) << 20);
+    }
+    ptab[P] = e;
+  }
+  __syncthreads();
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.xbytes, 0x00020000);
+  const unsigned wl0 = (unsigned)(size_t)(lptr4_t)wl + fr * 128 + ((fg ^ (fr >> 1)) << 4);
+  float bias4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias4[r] = (a.bias && fg * 4 + r < a.cout) ? a.bias[fg * 4 + r] : 0.f;
+
+  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const long mw = (long)tile * (64 * FM) + wave * (16 * FM);
+    // row decode: one 32-bit division chain for fragment 0 (host guarantees M < 2^31), the other fragments step 16 rows
+    // on with carries — 64-bit divisions per fragment cost more than the whole K loop of a 3^3 x 16-lane layer
+    int rd0[FM], rh0[FM], rw0[FM]; unsigned rbase[FM]; int yoff[FM];
+    {
+      unsigned t = (unsigned)(mw + fr);
+      int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+      int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+      int rd = (int)(t % (unsigned)a.RD); int n = (int)(t / (unsigned)a.RD);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const bool v = mw + i * 16 + fr < a.M;
+        rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
+        rbase[i] = v ? (unsigned)((n * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw) * 2) : IG4_OOB;
+        yoff[i] = v ? (int)(n * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh + (long)(rw * a.os[2] + a.oo[2]) * a.ysw) : -1;
+        rw += 16;
+        while (rw >= a.RW) { rw -= a.RW; if (++rh == a.RH) { rh = 0; if (++rd == a.RD) { rd = 0; ++n; } } }
+      }
+    }
+    f32x4 acc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4_t xa[2][FM][2];
+    auto fetch = [&](int ks, u32x4_t (&x)[FM][2]) {
+      const PieceInfo e0 = ptab[ks * 8 + fg], e1 = ptab[ks * 8 + 4 + fg];
+      const int d0 = (e0.disp & 1023) - 512, h0 = ((e0.disp >> 10) & 1023) - 512, w0 = ((e0.disp >> 20) & 1023) - 512;
+      const int d1 = (e1.disp & 1023) - 512, h1 = ((e1.disp >> 10) & 1023) - 512, w1 = ((e1.disp >> 20) & 1023) - 512;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bool ok0 = e0.disp >= 0, ok1 = e1.disp >= 0;
+        if (CHECK) {
+          ok0 &= ((unsigned)(rd0[i] + d0) < (unsigned)a.ID) & ((unsigned)(rh0[i] + h0) < (unsigned)a.IH) & ((unsigned)(rw0[i] + w0) < (unsigned)a.IW);
+          ok1 &= ((unsigned)(rd0[i] + d1) < (unsigned)a.ID) & ((unsigned)(rh0[i] + h1) < (unsigned)a.IH) & ((unsigned)(rw0[i] + w1) < (unsigned)a.IW);
+        }
+        x[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok0 ? rbase[i] + (unsigned)e0.off : IG4_OOB), 0, 0);
+        x[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok1 ? rbase[i] + (unsigned)e1.off : IG4_OOB), 0, 0);
+      }
+    };
+    auto mma = [&](int ks, u32x4_t (&x)[FM][2]) {
+      const bf16x8 w0 = *(const bf16x8*)(wl + ks * 1024 + fr * 64 + ((fg ^ (fr >> 1)) << 3));
+      const bf16x8 w1 = *(const bf16x8*)(wl + ks * 1024 + fr * 64 + (((fg + 4) ^ (fr >> 1)) << 3));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bf16x8 f0, f1;
+        __builtin_memcpy(&f0, &x[i][0], 16); __builtin_memcpy(&f1, &x[i][1], 16);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, f0, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, f1, acc[i], 0, 0, 0);
+      }
+    };
+    (void)wl0;
+    fetch(0, xa[0]);
+    for (int ks = 0; ks < nk; ks += 2) {
+      if (ks + 1 < nk) fetch(ks + 1, xa[1]);
+      mma(ks, xa[0]);
+      if (ks + 1 < nk) {
+        if (ks + 2 < nk) fetch(ks + 2, xa[0]);
+        mma(ks + 1, xa[1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (yoff[i] < 0) continue;
+      bf16_t* yrow = a.y + yoff[i];
+      const int c = fg * 4;
+      if (c >= a.cout_lanes) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (c + r < a.cout) v = act_fwd(acc[i][r] + bias4[r], a.act, a.slope);
+        o[r] = (short)f2bf(v);
+      }
+      *(bf16x4*)(yrow + c) = o;
+    }
+  }
+}
+
+// weights-resident thin kernel: Cout <= 16 and the packed matrix (plus the piece table) fits 128 KB of LDS
+bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p) {
+  if (p->cout > 16) return false;
+  const int krow = round_up(p->T[0] * p->T[1] * p->T[2] * X.lanes, 64);
+  return (size_t)krow * 32 + (size_t)(krow / 8) * sizeof(PieceInfo) <= 128 * 1024;
+}
+int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st) {
+  Igemm4Args a = a0;
+  constexpr int FM = 4;
+  a.tiles_m = (int)((a.M + 64 * FM - 1) / (64 * FM));
+  const size_t shm = (size_t)a.krow * 32 + (size_t)(a.krow / 8) * sizeof(PieceInfo);
+  // persistent workgroups: as many as fit the CUs (LDS-limited), every one stages the weights once
+  int per_cu = (int)((160 * 1024) / (shm + 1024)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+  int grid = 256 * per_cu; if (grid > a.tiles_m) grid = a.tiles_m;
+  rg_set_kernel_name("igemm_thin_kernel<%d,%d>", FM, (int)check);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)igemm_thin_kernel<FM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    hipFuncSetAttribute((const void*)igemm_thin_kernel<FM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    attr_done = true;
+  }
+  if (check) hipLaunchKernelGGL((igemm_thin_kernel<FM, true>), dim3(grid), dim3(256), shm, st, a);
+  else hipLaunchKernelGGL((igemm_thin_kernel<FM, false>), dim3(grid), dim3(256), shm, st, a);
   return RG_OK;
 }
