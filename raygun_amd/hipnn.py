@@ -206,8 +206,8 @@ class FusedSequential(nn.Sequential):
     """nn.Sequential (same indices / state_dict keys / len) whose forward fuses
     [pad] conv [InstanceNorm] [activation]  into conv-epilogue / norm-apply kernels."""
 
-    def run(self, x, residual=None):
-        mods = list(self)
+    def run(self, x, residual=None, upto=None):
+        mods = list(self)[:upto]
         i, n = 0, len(mods)
         while i < n:
             m = mods[i]

@@ -206,14 +206,20 @@ def profile_stop():
     return out
 
 
-def _timed(flops, fn):
+profile_shapes = False  # True: key the records by kernel name AND problem shape (diagnostics)
+
+
+def _timed(flops, fn, tag=None):
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    _prof.append((_lib.lib().rg_last_kernel_name().decode(), flops, e0, e1))
+    name = _lib.lib().rg_last_kernel_name().decode()
+    if profile_shapes and tag is not None:
+        name += " " + tag()
+    _prof.append((name, flops, e0, e1))
     return r
 
 
@@ -226,7 +232,8 @@ def _igemm(x, wp, bias, y, p):
     dx, dy = desc(x), desc(y)
     _timed(_conv_flops(p, x.shape[0], x.shape[1], y.shape[1]),
            lambda: _lib.check(_lib.lib().rg_conv3d_igemm(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
-                                                         _stream()), "rg_conv3d_igemm"))
+                                                         _stream()), "rg_conv3d_igemm"),
+           lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} R{tuple(p.R)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)}")
 
 
 def _wgrad(g, x, p, shape):
@@ -239,7 +246,8 @@ def _wgrad(g, x, p, shape):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
     _timed(_conv_flops(p, g.shape[0], x.shape[1], g.shape[1]),
            lambda: _lib.check(_lib.lib().rg_conv3d_wgrad(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p), 0,
-                                                         C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad"))
+                                                         C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad"),
+           lambda: f"g{tuple(g.shape)} x{tuple(x.shape)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)} ns{ns.value}")
     return dw
 
 
@@ -371,6 +379,38 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
         wf = weight.permute(0, 4, 2, 3, 1)  # (Cout, KW, KD, KH, 1): autograd maps the gradient back
         return _Conv3d.apply(xf, wf, bias, (stride[0], stride[1], 1), (0, 0, 0), act, float(slope))
     return _Conv3d.apply(x, weight, bias, stride, padding, act, float(slope))
+
+
+def conv3d_linear_pair(x, w_a, b_a, w_b, b_b, padding=0, act="none", slope=0.0):
+    """act(conv1x1(conv(x, w_a, b_a, padding), w_b, b_b)) for a stride-1 conv followed DIRECTLY by a 1x1x1 conv (no
+    norm/activation in between), evaluated as ONE convolution with the composed weights — the tail of every raygun
+    generator, Sequential(ResnetGenerator3D[..., Conv3d(ngf, ngf, 7)], Conv3d(ngf, output_nc, 1)) (networks/ResNet.py:338 +
+    systems/BaseSystem.py:209-224): 64->64 7^3 followed by 64->1 is 64x the FLOPs of the single 64->1 7^3 map it equals.
+
+      W'[p,c,t] = sum_m w_b[p,m] w_a[m,c,t]        b' = w_b b_a + b_b
+
+    The P-output conv with KW taps along W is run as a (P*KW)-output conv with (KD,KH,1) taps — one output channel per
+    (p, kw) — followed by the fixed diagonal gather y[p,w] = sum_kw z[p*KW+kw, w+kw] (a (1,1,KW) conv with one-hot weights):
+    the first stage has KW times fewer taps to re-read the 64-channel input for.  Everything is ordinary autograd over
+    ops.conv3d; the einsum/permute on the (tiny) weights carries the gradients back to w_a, b_a, w_b, b_b."""
+    padding = _triple(padding)
+    P, M = w_b.shape[0], w_b.shape[1]
+    KD, KH, KW = w_a.shape[2:]
+    wc = torch.einsum("pm,mcdhw->pcdhw", w_b.reshape(P, M).float(), w_a.float())        # (P, Cin, KD, KH, KW)
+    bc = None
+    if b_a is not None or b_b is not None:
+        bc = torch.zeros(P, dtype=torch.float32, device=w_a.device)
+        if b_a is not None:
+            bc = bc + w_b.reshape(P, M).float() @ b_a.float()
+        if b_b is not None:
+            bc = bc + b_b.float()
+    w1 = wc.permute(0, 4, 1, 2, 3).reshape(P * KW, wc.shape[1], KD, KH, 1)               # channel p*KW+kw <- tap kw
+    z = conv3d(x, w1, None, 1, padding, "none", 0.0)                                      # W extent grows by 2*pad_w
+    eye = torch.zeros(P, P * KW, 1, 1, KW, dtype=torch.float32, device=w_a.device)
+    for pp in range(P):
+        for k in range(KW):
+            eye[pp, pp * KW + k, 0, 0, k] = 1.0
+    return conv3d(z, eye, bc, 1, 0, act, slope)
 
 
 class _ConvTranspose3d(torch.autograd.Function):

@@ -59,6 +59,7 @@ class ResnetBlock3D(nn.Module):
 class ResnetGenerator3D(nn.Module):
     """ResNet.py:226-344."""
     _raygun_amd = True
+    _raygun_tail_ok = True  # forward is exactly self.model(input): RaygunSequential may split off the last conv
 
     def __init__(self, input_nc=1, output_nc=None, ngf=64, norm_layer=torch.nn.InstanceNorm3d, use_dropout=False,
                  n_blocks=6, padding_type="reflect", activation=torch.nn.ReLU, add_noise=False, n_downsampling=2):

@@ -19,8 +19,45 @@ from ... import hipnn, ops
 
 
 class RaygunSequential(hipnn.FusedSequential):
-    """nn.Sequential(net, 1x1 conv[, activation]) of get_network (BaseSystem.py:209-224) as one raygun_amd scope."""
+    """nn.Sequential(net, 1x1 conv[, activation]) of get_network (BaseSystem.py:209-224) as one raygun_amd scope.
+
+    When `net` ends in a plain stride-1 convolution (the generators do: Conv3d(ngf, ngf, 7), ResNet.py:338) that conv and
+    the 1x1 conv are one linear map; they are evaluated as a single composed convolution (ops.conv3d_linear_pair: same
+    parameters, same state_dict, gradients for all four tensors), 64x fewer FLOPs for ngf = 64, output_nc = 1.
+    RAYGUN_AMD_FUSE_TAIL=0 evaluates the two layers one after the other."""
     _raygun_amd = True
+
+    def _linear_tail(self):
+        mods = list(self)
+        if len(mods) < 2 or os.environ.get("RAYGUN_AMD_FUSE_TAIL", "1") == "0":
+            return None
+        inner = getattr(mods[0], "model", None)
+        if not isinstance(inner, hipnn.FusedSequential) or len(inner) == 0:
+            return None
+        a, b = inner[-1], mods[1]
+        if not isinstance(a, hipnn.Conv3d) or not isinstance(b, hipnn.Conv3d):
+            return None
+        if tuple(b.kernel_size) != (1, 1, 1) or tuple(b.stride) != (1, 1, 1) or tuple(a.stride) != (1, 1, 1):
+            return None
+        if a.padding_mode != "zeros" or a.groups != 1 or b.groups != 1 or any(d != 1 for d in a.dilation):
+            return None
+        if b.out_channels * a.kernel_size[2] * 2 > a.out_channels:  # only when the composed map is much thinner
+            return None
+        return inner, a, b
+
+    def run(self, x, residual=None, upto=None):
+        tail = self._linear_tail() if upto is None and residual is None else None
+        if tail is None or not getattr(type(list(self)[0]), "_raygun_tail_ok", False):
+            return super().run(x, residual, upto)
+        inner, a, b = tail
+        mods = list(self)
+        x = inner.run(ops.enter(x), upto=len(inner) - 1)
+        act = hipnn.act_of(mods[2]) if len(mods) > 2 else None
+        x = ops.conv3d_linear_pair(x, a.weight, a.bias, b.weight, b.bias, a._pads(), *(act if act is not None else ("none", 0.0)))
+        rest = mods[3:] if act is not None else mods[2:]
+        for m in rest:
+            x = m(x)
+        return x
 
 
 class BaseSystem:
