@@ -58,15 +58,16 @@ int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, f
  *   transposed == 1 : ConvTranspose3d weight (Cin,Cout,KD,KH,KW) [networks/ResNet.py:325-333]
  * mode 0 (forward operand of a conv / dgrad operand of a convT): rows = dim0 ... see conv.hip.
  * Packed layout: bf16 [rows16][ntaps][redK], rows16 = rows rounded up to 16, redK = reduced channels rounded
- * up to red_align (32 or 64), zero filled.  `swap` selects which of the two channel dims is the row dim (0: dim0 rows, 1: dim1 rows).
+ * up to red_align (8, 32 or 64), zero filled; red_align 1 = FLAT: bf16 [rows16][(tap, reduced channels rounded up to 8), the row padded
+ * once to a multiple of 64] (no per-tap padding).  `swap` selects which of the two channel dims is the row dim (0: dim0 rows, 1: dim1 rows).
  * The tap subset is {k0 + kstep*j, j < ntap} per dim (parity classes of strided transposed convs). */
 typedef struct {
   int32_t dim0, dim1, K[3];
   int32_t swap;
   int32_t k0[3], kstep[3], ntap[3];
-  int32_t red_align; /* reduced-channel padding per tap: 8, 32 or 64 = rg_conv3d_kalign(reduced, rows); 0 means 32 */
+  int32_t red_align; /* = rg_conv3d_kalign(reduced, rows): 64/32/8 = reduced-channel padding per tap, 1 = FLAT rows; 0 means 32 */
 } rg_pack_params;
-/* K alignment per tap that rg_conv3d_igemm expects for a problem with `cin` reduced and `cout` produced channels */
+/* Packing mode (rg_pack_params.red_align) that rg_conv3d_igemm expects for a problem with `cin` reduced and `cout` produced channels */
 int rg_conv3d_kalign(int cin, int cout);
 int64_t rg_pack_weights_bytes(const rg_pack_params* p);
 int rg_pack_weights(const float* w, void* packed_bf16, const rg_pack_params* p, rg_stream s);
