@@ -97,7 +97,10 @@ def build_cyclegan(dev, size, seed):
         s.optimizer.step()
         return loss
 
-    return step, dict(model="CycleGAN link: ResNet(ngf64,6 blocks,2 down,IN)+PatchD(ngf64,3 layers) lsgan", params=71848196)
+    fused = os.environ.get("RAYGUN_AMD_FUSE_TAIL", "1") != "0"
+    return step, dict(model="CycleGAN link: ResNet(ngf64,6 blocks,2 down,IN)+PatchD(ngf64,3 layers) lsgan"
+                            + ("; generator tail Conv3d(64,64,7)+1x1 evaluated as one composed conv (DESIGN.md 3a)" if fused else ""),
+                      params=71848196)
 
 
 def pmc_traffic(kernel_name):
