@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, (FM >= 4 ? 2 : 3)) void igemm4_kernel(Igemm4Ar
     asm volatile("" ::: "memory");
     store_b(stage ^ 1);           // weights of step ks+1: registers -> the buffer whose readers finished before the barrier
     load_b();                     // weights of step ks+2 -> registers
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // keep the hand-counted fragment reads alone on the counter
+    // no wait for the ds_writes above: LDS operations of a wave complete in order, so the counted waits below (which
+    // allow the 1-2 YOUNGEST reads to be outstanding) already cover them
     const unsigned b0 = b_lane + stage * (BSTAGE * 2), b1 = b0 ^ 64u;
     bf16x8 wf[3];
     ld4_16<0>(wf[0], b0);

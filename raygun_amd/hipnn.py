@@ -22,6 +22,8 @@ _tls = threading.local()
 def scope():
     """Yields True for the outermost raygun_amd module of the current call stack."""
     depth = getattr(_tls, "depth", 0)
+    if depth == 0:
+        ops.lift_reset()
     _tls.depth = depth + 1
     try:
         yield depth == 0
@@ -173,14 +175,109 @@ class MaxPool3d(nn.MaxPool3d):
 
 
 def passthrough(fn, x, *args, **kwargs):
-    """Run a torch op that has no HIP kernel here (dropout, noise blocks, affine norms) on a dense fp32 view."""
+    """Run a torch op that has no HIP kernel here (dropout, noise blocks, affine norms) on a dense fp32 view
+    (4-D again if the network is a lifted 2-D one; the next raygun_amd layer re-enters)."""
     dense = ops.leave(x) if ops.is_cl(x) else x
     return fn(dense, *args, **kwargs)
 
 
+# ---- 2-D twins: the same kernels on a (N,C,1,H,W) view -------------------------------------------------------------
+def _pair(v):
+    return (int(v),) * 2 if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+class Conv2d(nn.Conv2d):
+    """torch.nn.Conv2d as a 3-D convolution with a (1,KH,KW) kernel."""
+
+    def _pads(self):
+        if isinstance(self.padding, str):
+            if self.padding == "valid":
+                return (0, 0)
+            tot = [d * (k - 1) for d, k in zip(self.dilation, self.kernel_size)]
+            if any(t % 2 for t in tot):
+                raise RuntimeError("raygun_amd.Conv2d: padding='same' needs odd kernels")
+            return tuple(t // 2 for t in tot)
+        return tuple(self.padding)
+
+    def run(self, x, act="none", slope=0.0):
+        if self.groups != 1 or any(d != 1 for d in self.dilation):
+            raise RuntimeError("raygun_amd.Conv2d: groups/dilation != 1 are not built (use torch.nn.Conv2d)")
+        if self.padding_mode not in ("zeros", "reflect"):
+            raise RuntimeError(f"raygun_amd.Conv2d: padding_mode {self.padding_mode!r} is not built")
+        x = ops.enter(x)
+        pads = self._pads()
+        if self.padding_mode == "reflect" and any(pads):
+            x = ops.pad3d(x, (0,) + pads, "reflect")
+            pads = (0, 0)
+        return ops.conv3d(x, self.weight.unsqueeze(2), self.bias, (1,) + tuple(self.stride), (0,) + pads, act, slope)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def run(self, x, act="none", slope=0.0):
+        if self.groups != 1 or any(d != 1 for d in self.dilation):
+            raise RuntimeError("raygun_amd.ConvTranspose2d: groups/dilation != 1 are not built")
+        return ops.conv_transpose3d(ops.enter(x), self.weight.unsqueeze(2), self.bias, (1,) + tuple(self.stride),
+                                    (0,) + tuple(self.padding), (0,) + tuple(self.output_padding), act, slope)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class InstanceNorm2d(nn.InstanceNorm2d):
+    """As InstanceNorm3d: the plain form runs on the HIP kernels, affine / running-stats forms on torch's op."""
+
+    def hip_ok(self):
+        return not self.affine and not self.track_running_stats
+
+    def run(self, x, act="none", slope=0.0, residual=None):
+        if not self.hip_ok():
+            y = passthrough(super().forward, x)
+            if residual is not None:
+                y = ops.add(ops.enter(y), residual)
+            return ops.activation(ops.enter(y), act, slope)
+        return ops.instance_norm(ops.enter(x), self.eps, act, slope, residual)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class ReflectionPad2d(nn.ReflectionPad2d):
+    @scoped
+    def forward(self, x):
+        p = self.padding
+        p = (p,) * 4 if isinstance(p, int) else tuple(p)
+        if not (p[0] == p[1] and p[2] == p[3]):
+            raise RuntimeError(f"raygun_amd.ReflectionPad2d: only symmetric padding is supported, got {p}")
+        return ops.pad3d(ops.enter(x), (0, p[2], p[0]), "reflect")
+
+
+class MaxPool2d(nn.MaxPool2d):
+    @scoped
+    def forward(self, x):
+        ks, st = _pair(self.kernel_size), _pair(self.stride)
+        if ks != st or self.padding not in (0, (0, 0)) or self.ceil_mode:
+            raise RuntimeError("raygun_amd.MaxPool2d: only kernel == stride, no padding, floor mode is built")
+        return ops.maxpool3d(ops.enter(x), (1,) + ks)
+
+
 _HIP_LAYER = {"Conv3d": Conv3d, "ConvTranspose3d": ConvTranspose3d, "InstanceNorm3d": InstanceNorm3d,
               "ReflectionPad3d": ReflectionPad3d, "MaxPool3d": MaxPool3d, "ReLU": ReLU, "LeakyReLU": LeakyReLU,
-              "Sigmoid": Sigmoid, "Tanh": Tanh}
+              "Sigmoid": Sigmoid, "Tanh": Tanh, "Conv2d": Conv2d, "ConvTranspose2d": ConvTranspose2d,
+              "InstanceNorm2d": InstanceNorm2d, "ReflectionPad2d": ReflectionPad2d, "MaxPool2d": MaxPool2d}
+_CONVS = (Conv3d, ConvTranspose3d, Conv2d, ConvTranspose2d)
+_NORMS = (InstanceNorm3d, InstanceNorm2d)
+
+
+def layers(nd):
+    """(Conv, ConvTranspose, InstanceNorm, ReflectionPad, MaxPool) twins for 2-D or 3-D networks."""
+    return {3: (Conv3d, ConvTranspose3d, InstanceNorm3d, ReflectionPad3d, MaxPool3d),
+            2: (Conv2d, ConvTranspose2d, InstanceNorm2d, ReflectionPad2d, MaxPool2d)}[nd]
 
 
 def hip_layer(factory):
@@ -199,7 +296,7 @@ def hip_layer(factory):
 def is_instance_norm_factory(factory, nd=3):
     """`use_bias = norm_layer == InstanceNorm3d` of the reference (networks/ResNet.py:259-262), for either class."""
     base = factory.func if isinstance(factory, functools.partial) else factory
-    return base in (getattr(nn, f"InstanceNorm{nd}d"), InstanceNorm3d)
+    return base in (getattr(nn, f"InstanceNorm{nd}d"), InstanceNorm3d, InstanceNorm2d)
 
 
 class FusedSequential(nn.Sequential):
@@ -212,12 +309,12 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             last = lambda j: j >= n  # noqa: E731
-            if isinstance(m, (Conv3d, ConvTranspose3d)):
+            if isinstance(m, _CONVS):
                 nxt = mods[i + 1] if i + 1 < n else None
                 a = act_of(nxt) if nxt is not None else None
                 if a is not None:
                     x = m.run(x, a[0], a[1]); i += 2
-                elif isinstance(nxt, InstanceNorm3d):
+                elif isinstance(nxt, _NORMS):
                     x = m.run(x)
                     a2 = act_of(mods[i + 2]) if i + 2 < n else None
                     if a2 is not None:
@@ -229,7 +326,7 @@ class FusedSequential(nn.Sequential):
                             residual = None
                 else:
                     x = m.run(x); i += 1
-            elif isinstance(m, InstanceNorm3d):
+            elif isinstance(m, _NORMS):
                 a = act_of(mods[i + 1]) if i + 1 < n else None
                 if a is not None:
                     x = m.run(x, a[0], a[1]); i += 2
@@ -238,7 +335,7 @@ class FusedSequential(nn.Sequential):
             elif act_of(m) is not None and not isinstance(m, (ReLU, LeakyReLU, Sigmoid, Tanh)):
                 a = act_of(m)  # a plain torch.nn activation instance handed in by the user
                 x = ops.activation(x, a[0], a[1]); i += 1
-            elif isinstance(m, (ReflectionPad3d, MaxPool3d, ReLU, LeakyReLU, Sigmoid, Tanh, FusedSequential)) or \
+            elif isinstance(m, (ReflectionPad3d, MaxPool3d, ReflectionPad2d, MaxPool2d, ReLU, LeakyReLU, Sigmoid, Tanh, FusedSequential)) or \
                     getattr(m, "_raygun_amd", False):
                 x = m(x); i += 1
             elif isinstance(m, nn.Identity):

@@ -8,6 +8,8 @@ rg_copy_convert.  There is no CPU path: CPU tensors raise.
 """
 import ctypes as C
 
+import threading
+
 import torch
 
 from . import _lib
@@ -117,21 +119,40 @@ class _FromCL(torch.autograd.Function):
         return to_cl(g)
 
 
+_lift = threading.local()  # .on: a 4-D (N,C,H,W) tensor entered the current outermost scope and was lifted to D = 1
+
+
+def lift_reset():
+    _lift.on = False
+
+
+def lifted():
+    return getattr(_lift, "on", False)
+
+
 def enter(x):
-    """Network entry: user tensor -> channels-last bf16, differentiable."""
+    """Network entry: user tensor -> channels-last bf16, differentiable.  2-D (N,C,H,W) tensors travel as (N,C,1,H,W):
+    every 2-D layer is its 3-D kernel with one plane (reference 2-D nets: networks/ResNet.py:6-223,
+    NLayerDiscriminator.py:5-101)."""
     _require_cuda(x, "enter")
+    if x.dim() == 4:
+        _lift.on = True
+        x = x.unsqueeze(2)
     if is_cl(x):
         return x
     return _ToCL.apply(x)
 
 
 def leave(x):
-    """Network exit: channels-last bf16 -> fp32 NCDHW contiguous, differentiable."""
+    """Network exit: channels-last bf16 -> fp32 NCDHW contiguous (NCHW if the input was 2-D), differentiable."""
     if isinstance(x, (list, tuple)):
         return type(x)(leave(t) for t in x)
     if x is None or not is_cl(x):
         return x
-    return _FromCL.apply(x)
+    y = _FromCL.apply(x)
+    if lifted() and y.dim() == 5 and y.shape[2] == 1:
+        y = y.squeeze(2)
+    return y
 
 
 # ---------------------------------------------------------------------------------------------- weights

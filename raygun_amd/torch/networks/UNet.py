@@ -31,7 +31,7 @@ def _conv_cls(dims):
     if dims == 3:
         return hipnn.Conv3d
     if dims == 2:
-        raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet (SURVEY.md §8f rank 1); kernel rank 3 only")
+        return hipnn.Conv2d  # the 3-D kernels on a (N,C,1,H,W) view
     raise RuntimeError("%dD convolution not implemented" % dims)  # UNet.py:84-85
 
 
@@ -54,7 +54,7 @@ class ConvPass(nn.Module):
             if residual and i == 0:
                 groups = input_nc if input_nc < output_nc else output_nc
                 # grouped 1x1 map of the residual variant: torch's own op (not on the benchmark path)
-                self.x_init_map = nn.Conv3d(input_nc, output_nc, tuple(np.ones(self.dims, dtype=int)), padding=padding,
+                self.x_init_map = getattr(nn, f"Conv{self.dims}d")(input_nc, output_nc, tuple(np.ones(self.dims, dtype=int)), padding=padding,
                                             padding_mode=padding_mode, bias=False, groups=groups)
             if norm_layer is not None:
                 layers.append(norm_layer(output_nc))
@@ -73,7 +73,7 @@ class ConvPass(nn.Module):
         res = self.conv_pass(x)
         init_x = ops.enter(hipnn.passthrough(self.x_init_map, x))
         if self.padding.lower() == "valid":
-            init_x = self.crop(init_x, res.size()[-self.dims:])
+            init_x = self.crop(init_x, res.size()[-3:] if res.dim() == 5 else res.size()[-self.dims:])
         y = ops.add(init_x, res)
         a = hipnn.act_of(self.activation)
         return ops.activation(y, a[0], a[1]) if a is not None else hipnn.passthrough(self.activation, y)
@@ -111,10 +111,12 @@ class MaxDownsample(nn.Module):
         self.dims = len(downsample_factor)
         self.downsample_factor = downsample_factor
         self.flexible = flexible
-        if self.dims not in (3, 4):
-            raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet; 3-D pooling only")
-        f = tuple(int(v) for v in downsample_factor)[-3:]
-        self.down = hipnn.MaxPool3d(f, stride=f)
+        if self.dims == 2:
+            f = tuple(int(v) for v in downsample_factor)
+            self.down = hipnn.MaxPool2d(f, stride=f)
+        else:
+            f = tuple(int(v) for v in downsample_factor)[-3:]
+            self.down = hipnn.MaxPool3d(f, stride=f)
 
     @hipnn.scoped
     def forward(self, x):
@@ -149,10 +151,10 @@ class Upsample(nn.Module):
         self.dims = len(scale_factor)
         self.scale_factor = tuple(int(s) for s in scale_factor)
         self.mode = mode
-        if self.dims != 3:
-            raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet; 3-D upsampling only")
+        if self.dims not in (2, 3):
+            raise NotImplementedError("raygun_amd.Upsample: 2-D and 3-D only")
         if mode == "transposed_conv":
-            self.up = hipnn.ConvTranspose3d(input_nc, output_nc, kernel_size=self.scale_factor, stride=self.scale_factor)
+            self.up = hipnn.layers(self.dims)[1](input_nc, output_nc, kernel_size=self.scale_factor, stride=self.scale_factor)
         else:
             if mode != "nearest":
                 raise NotImplementedError(f"raygun_amd.Upsample: mode {mode!r} is not built (nearest / transposed_conv)")
@@ -160,7 +162,7 @@ class Upsample(nn.Module):
 
     def target_shape(self, spatial_shape, factor, kernel_sizes):
         """crop_to_factor (UNet.py:275-325): largest n with n*f + c <= s, c = sum(ks-1)."""
-        convolution_crop = tuple(sum(ks[d] - 1 for ks in kernel_sizes) for d in range(self.dims))
+        convolution_crop = tuple(sum(ks[d] - 1 for ks in kernel_sizes) for d in range(len(factor)))
         ns = (int(math.floor(float(s - c) / f)) for s, c, f in zip(spatial_shape, convolution_crop, factor))
         target = tuple(n * f + c for n, c, f in zip(ns, convolution_crop, factor))
         if target != tuple(spatial_shape):
@@ -174,15 +176,18 @@ class Upsample(nn.Module):
 
     @hipnn.scoped
     def forward(self, f_left, g_out):
+        f_left, g_out = ops.enter(f_left), ops.enter(g_out)  # 2-D tensors travel as (N,C,1,H,W)
+        lift = (1,) * (3 - self.dims)
         if self.mode == "transposed_conv":
             g_up, factor = self.up(g_out), (1, 1, 1)
             up_shape = tuple(g_up.shape[-3:])
         else:
-            g_up, factor = g_out, self.scale_factor
+            g_up, factor = g_out, lift + self.scale_factor
             up_shape = tuple(a * b for a, b in zip(g_out.shape[-3:], factor))
         target = up_shape
         if self.crop_factor is not None:
-            target = self.target_shape(up_shape, self.crop_factor, self.next_conv_kernel_sizes)
+            target = self.target_shape(up_shape, lift + tuple(self.crop_factor),
+                                       [lift + tuple(ks) for ks in self.next_conv_kernel_sizes])
         return ops.upcat(f_left, g_up, factor, target)
 
 

@@ -144,7 +144,7 @@ class BaseSystem:
         elif net_type == "resnet":
             net = networks.ResNet(self.ndims, **net_kwargs)
         elif net_type == "patchdiscriminator":
-            net_kwargs["norm_layer"] = functools.partial(hipnn.InstanceNorm3d, affine=False, track_running_stats=False)
+            net_kwargs["norm_layer"] = functools.partial(hipnn.layers(self.ndims)[2], affine=False, track_running_stats=False)
             net = networks.NLayerDiscriminator(self.ndims, **net_kwargs)
             add_final = False
         elif hasattr(networks, net_type):
@@ -152,10 +152,10 @@ class BaseSystem:
         else:
             raise RuntimeError(f"Unknown network type requested: {net_type}")
         if add_final:
-            if self.ndims != 3:
-                raise NotImplementedError("raygun_amd: the 2-D HIP path is not built yet (SURVEY.md §8f rank 1)")
-            layers = [net, hipnn.Conv3d(net_kwargs["ngf"], output_nc, (1,) * self.ndims,
-                                        padding="valid" if "padding_type" not in net_kwargs else net_kwargs["padding_type"])]
+            if self.ndims not in (2, 3):
+                raise ValueError(self.ndims, "Only 2D or 3D currently implemented.")
+            layers = [net, hipnn.layers(self.ndims)[0](net_kwargs["ngf"], output_nc, (1,) * self.ndims,
+                                                       padding="valid" if "padding_type" not in net_kwargs else net_kwargs["padding_type"])]
             if final_activation is not None:
                 layers.append(hipnn.hip_layer(final_activation)())  # the reference appends the class itself (:221-222)
             net = RaygunSequential(*layers)

@@ -18,12 +18,16 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def build_system(loss_type, loss_kwargs=None):
+def build_system(loss_type, loss_kwargs=None, nd=3):
     from raygun_amd.torch.systems import CycleGAN
-    IN3 = functools.partial(torch.nn.InstanceNorm3d)
-    cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
-               gnet_kwargs=dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN3, padding_type="same"),
-               dnet_kwargs=dict(input_nc=1, ngf=8, n_layers=3, kw=4), loss_type=loss_type, loss_kwargs=loss_kwargs or {},
+    IN = functools.partial(getattr(torch.nn, f"InstanceNorm{nd}d"))
+    gk = dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN, padding_type="same")
+    dk = dict(input_nc=1, ngf=8, n_layers=3, kw=4)
+    if nd == 2:  # BASELINE config[0] (tests/test_oracle_golden.py::test_cyclegan_2d_256_plumbing_config0)
+        gk = dict(input_nc=1, ngf=16, n_blocks=9, n_downsampling=0, norm_layer=IN, padding_type="same")
+        dk = dict(input_nc=1, ngf=16, n_layers=4)
+    cfg = dict(common_voxel_size=[1, 1, 1][:nd], ndims=nd, gnet_type="resnet",
+               gnet_kwargs=gk, dnet_kwargs=dk, loss_type=loss_type, loss_kwargs=loss_kwargs or {},
                g_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4))
     s = CycleGAN(cfg)
     s.setup_networks()
@@ -37,11 +41,11 @@ def build_system(loss_type, loss_kwargs=None):
     return s, dev
 
 
-def run_steps(s, dev, iters):
+def run_steps(s, dev, iters, shape=(1, 1, 32, 32, 32)):
     recs = []
     for it in range(iters):
-        A = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 90 + 2 * it)).to(dev)
-        B = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 91 + 2 * it)).to(dev)
+        A = torch.from_numpy(synth.uniform(shape, 90 + 2 * it)).to(dev)
+        B = torch.from_numpy(synth.uniform(shape, 91 + 2 * it)).to(dev)
         s.optimizer.zero_grad()
         fB, cB, fA, cA = s.model(real_A=A, real_B=B)
         tot = s.loss(A, fA, cA, B, fB, cB)
@@ -83,3 +87,20 @@ def test_total_loss_backward_is_noop_and_weights_move():
     recs, _ = run_steps(s, dev, 1)
     moved = sum(float((p.detach() - q).abs().sum()) for p, q in zip(s.netG1.parameters(), w0))
     assert moved > 0 and all(np.isfinite(v) for v in recs[0].values())
+
+
+def test_train_step_loss_trajectory_2d_config0():
+    """BASELINE config[0] on the GPU: 2-D CycleGAN (ResnetGenerator2D 9 blocks + 4-layer PatchGAN2D, split loss) at 256x256 —
+    every 2-D layer is its 3-D kernel on a (N,C,1,H,W) view."""
+    fx = np.load(os.path.join(G, "cyclegan_step_split_2d256.npz"))
+    ref = json.loads(str(fx["loss_dicts"]))
+    s, dev = build_system("split", None, nd=2)
+    assert list(s.model.state_dict().keys()) == json.loads(str(fx["meta"]))["state_keys_model"]
+    recs, fB = run_steps(s, dev, len(ref), (1, 1, 256, 256))
+    assert fB.dim() == 4 and fB.dtype == torch.float32 and tuple(fB.shape) == (1, 1, 256, 256)
+    for it, (mine, theirs) in enumerate(zip(recs, ref)):
+        assert set(mine) == set(theirs)
+        tol = 0.02 if it == 0 else 0.06
+        for k in theirs:
+            scale = max(abs(theirs[k]), 0.05, abs(theirs[k] - ref[0][k]))
+            assert abs(mine[k] - theirs[k]) <= tol * scale, (it, k, mine[k], theirs[k])
