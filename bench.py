@@ -55,7 +55,11 @@ def build_unet(dev, size, seed):
     gt_l = torch.from_numpy(synth.uniform((1, 10, out, out, out), 242 + seed, 0, 1)).to(dev)
     w_a, w_l = torch.ones_like(gt_a), torch.ones_like(gt_l)
 
+    attached = []
+
     def step(sync):
+        if not attached:  # overlap the gradient all-reduce with the backward pass (no-op at world size 1)
+            sync.attach(model.parameters()); attached.append(True)
         opt.zero_grad(set_to_none=True)
         affs, lsds = model(raw)
         loss = loss_fn(lsds, gt_l, w_l, affs, gt_a, w_a)

@@ -23,7 +23,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RAYGUN_AMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available() and local >= torch.cuda.device_count():
+            local %= torch.cuda.device_count()  # more ranks than devices: rehearsal on a smaller box (use gloo; RCCL refuses shared devices)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -37,26 +39,58 @@ def world_size():
 
 
 class GradSync:
-    """Callable(list_of_params): average .grad over all ranks (no-op for world size 1)."""
+    """Callable(list_of_params): average .grad over all ranks (no-op for world size 1).
+
+    `attach(params)` additionally overlaps the exchange with the backward pass: a post-accumulate-grad hook starts the
+    asynchronous all-reduce of a parameter's gradient the moment autograd has produced it (RCCL runs it on its own stream
+    while the remaining backward kernels execute), and the call before the optimiser step only waits and scales.  For
+    the U-Net 70 % of the 1 GB of gradients is ready half-way through the backward pass.  Only valid where every
+    attached parameter receives its gradient in ONE backward pass per step (not for the split CycleGAN losses)."""
 
     def __init__(self, group=None):
         self.group = group
+        self._pending = {}   # id(param) -> (grad tensor, work handle)
+        self._hooks = []
+
+    def attach(self, params):
+        if world_size() == 1:
+            return self
+        for p in params:
+            if p.requires_grad:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        return self
+
+    def detach(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def _on_grad(self, p):
+        g = p.grad
+        if g is None:
+            return
+        if not g.is_contiguous():
+            raise RuntimeError("raygun_amd.GradSync: gradients must be contiguous")
+        self._pending[id(p)] = (g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def __call__(self, params):
         ws = world_size()
         if ws == 1:
             return
-        grads = [p.grad for p in params if p.grad is not None]
-        grads.sort(key=lambda g: -g.numel())
-        handles = []
-        for g in grads:
+        params = [p for p in params if p.grad is not None]
+        started = [self._pending.pop(id(p)) for p in params if id(p) in self._pending]
+        done = {id(g) for g, _ in started}
+        rest = [p.grad for p in params if id(p.grad) not in done]
+        rest.sort(key=lambda g: -g.numel())
+        handles = [h for _, h in started]
+        for g in rest:
             if not g.is_contiguous():
                 raise RuntimeError("raygun_amd.GradSync: gradients must be contiguous")
             handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in handles:
             h.wait()
         inv = 1.0 / ws
-        torch._foreach_mul_(grads, inv)
+        torch._foreach_mul_([g for g, _ in started] + rest, inv)
 
 
 def broadcast_parameters(module, src=0):

@@ -11,7 +11,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from raygun_amd import parallel
     parallel.init_from_env(backend="gloo")
@@ -20,9 +20,15 @@ def _worker(rank, world, port, out):
     parallel.broadcast_parameters(net)
     g = torch.Generator().manual_seed(7)
     data = torch.randn(world, 1, 8, 8, 8, generator=g)  # same on all ranks; rank r trains on sample r
+    sync = parallel.GradSync()
+    if overlap:  # all-reduces start from post-accumulate-grad hooks during backward; the call only waits and scales
+        sync.attach(net.parameters())
     loss = net(data[rank:rank + 1]).pow(2).mean()
     loss.backward()
-    parallel.GradSync()(list(net.parameters()))
+    if overlap:
+        assert len(sync._pending) == len(list(net.parameters()))
+    sync(list(net.parameters()))
+    assert not sync._pending
     # reference: one process, whole batch (mean over equal-sized samples == mean of per-sample means)
     ref = torch.nn.Sequential(torch.nn.Conv3d(1, 3, 3), torch.nn.InstanceNorm3d(3), torch.nn.ReLU(), torch.nn.Conv3d(3, 1, 1))
     ref.load_state_dict(net.state_dict())
@@ -33,11 +39,15 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_gradsync_equals_big_batch_and_sharding():
+import pytest
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_gradsync_equals_big_batch_and_sharding(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
