@@ -137,6 +137,13 @@ int rg_pad3d_bwd(const rg_tensor* gy, const rg_tensor* gx, const int32_t pad[3],
 /* ---- residual add  y = a + b  (ResnetBlock3D.forward, ResNet.py:436-443) */
 int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream s);
 
+/* ---- in-plane taps <-> channels of a one-channel volume (build-owned helpers of the 7^3 stem / composed tail,
+ * networks/ResNet.py:283,338): spread  y[n,d,h,w][kh*KW+kw] = x[n,d,h+s*kh,w+s*kw][0] (0 outside x);
+ * sum  y[n,d,h,w][0] = bias[0] + sum_{kh,kw} x[n,d,h+s*kh,w+s*kw][kh*KW+kw] (terms outside x dropped); s = sign (+1/-1).
+ * x/y: bf16 channels-last, one of them 1 channel, the other KH*KW channels, equal batch and depth. */
+int rg_diag_spread(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, rg_stream s);
+int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, const float* bias, rg_stream s);
+
 /* ---- losses: value (fp32 scalar in out[0]) and gradient wrt pred in one pass.
  * kind 0: mean((p-t)^2) vs constant target  (GANLoss lsgan, losses/GANLoss.py:24-25,56-58)
  * kind 1: SmoothL1(beta=1) mean vs tensor t  (LinkCycleLoss.py:22,99-106)

@@ -470,6 +470,77 @@ extern "C" int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y
   return RG_OK;
 }
 
+// ---------------------------------------------------------------------------- (kh,kw) taps <-> channels of a 1-channel volume
+// A C-channel conv whose other side has ONE channel (the generator's 7^3 stem and its composed 64->1 tail) re-reads the
+// C-channel tensor once per tap.  Folding the KH*KW in-plane taps of the one-channel side into channels leaves a KD-tap
+// convolution between C and KH*KW channels (49x fewer passes over the wide tensor for 7^3) plus these two cheap maps:
+//   spread: y[n,d,h,w][kh*KW+kw] = x[n,d,h + s*kh, w + s*kw][0]   (0 outside x)
+//   sum   : y[n,d,h,w][0] = bias + sum_{kh,kw} x[n,d,h + s*kh, w + s*kw][kh*KW+kw]   (terms outside x dropped)
+// s = +1: im2col over (h,w) / the gather that finishes a conv;  s = -1: their adjoints.
+__global__ void diag_spread_kernel(CL5 x, CL5 y, int KH, int KW, int sgn) {
+  const long nvox = (long)y.N * y.D * y.H * y.W;
+  const int ngrp = y.lanes / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox * ngrp; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % ngrp); long t = i / ngrp;
+    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k, kh = c / KW, kw = c - kh * KW;
+      const int hh = h + sgn * kh, ww = w + sgn * kw;
+      bf16_t v = 0;
+      if (c < KH * KW && (unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) v = x.p[n * x.sn + d * x.sd + hh * x.sh + ww * x.sw];
+      o[k] = (short)v;
+    }
+    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + g * 8) = o;
+  }
+}
+__global__ void diag_sum_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, const float* bias) {
+  const long nvox = (long)y.N * y.D * y.H * y.W;
+  const float b = bias ? bias[0] : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+    float acc = b;
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hh = h + sgn * kh;
+      if ((unsigned)hh >= (unsigned)x.H) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ww = w + sgn * kw;
+        if ((unsigned)ww < (unsigned)x.W) acc += bf2f(x.p[n * x.sn + d * x.sd + hh * x.sh + ww * x.sw + kh * KW + kw]);
+      }
+    }
+    bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    o[0] = (short)f2bf(acc);
+    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw) = o;
+  }
+}
+static int diag_check(const rg_tensor* one, const rg_tensor* many, CL5* O, CL5* M, int KH, int KW, const char* what) {
+  int rc;
+  if ((rc = rg_as_cl5(one, O, what)) || (rc = rg_as_cl5(many, M, what))) return rc;
+  if (KH < 1 || KW < 1 || O->C != 1 || M->C != KH * KW || O->N != M->N || O->D != M->D) {
+    rg_set_error("%s: expects a 1-channel and a KH*KW-channel tensor with equal batch and depth", what);
+    return RG_ERR_BAD_SHAPE;
+  }
+  return RG_OK;
+}
+extern "C" int rg_diag_spread(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, rg_stream s) {
+  CL5 X, Y; int rc;
+  if ((rc = diag_check(x, y, &X, &Y, kh, kw, "diag_spread"))) return rc;
+  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
+  hipLaunchKernelGGL(diag_spread_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, const float* bias, rg_stream s) {
+  CL5 X, Y; int rc;
+  if ((rc = diag_check(y, x, &Y, &X, kh, kw, "diag_sum"))) return rc;
+  const long total = (long)Y.N * Y.D * Y.H * Y.W;
+  hipLaunchKernelGGL(diag_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
 // ---------------------------------------------------------------------------- fused Adam (torch.optim.Adam, no amsgrad)
 __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
                                          float bc1, float bc2_sqrt, float gscale) {

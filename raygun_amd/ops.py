@@ -8,6 +8,7 @@ rg_copy_convert.  There is no CPU path: CPU tensors raise.
 """
 import ctypes as C
 
+import os
 import threading
 
 import torch
@@ -395,6 +396,17 @@ def _fold_w(x, kw, stride_w, pad):
 
 def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
     stride, padding = _triple(stride), _triple(padding)
+    khw = weight.shape[3] * weight.shape[4]
+    if (weight.shape[1] == 1 and x.shape[1] == 1 and x.is_cuda and stride == (1, 1, 1) and 16 < khw <= 64 and weight.shape[0] > 16
+            and os.environ.get("RAYGUN_AMD_FOLD_HW", "1") != "0"):
+        # one-channel input, big in-plane kernel (the generator's 7^3 stem): (kh,kw) taps -> channels, KD taps remain
+        x = enter(x)
+        if any(padding):
+            x = pad3d(x, padding, "zeros")
+        kd, kh, kw = weight.shape[2:]
+        xf = _DiagSpread.apply(x, kh, kw, 1, x.shape[3] - kh + 1, x.shape[4] - kw + 1)
+        wf = weight.permute(0, 3, 4, 2, 1).reshape(weight.shape[0], kh * kw, kd, 1, 1)  # [cout][(kh,kw)][kd]
+        return _Conv3d.apply(xf, wf, bias, (1, 1, 1), (0, 0, 0), act, float(slope))
     if weight.shape[1] == 1 and 1 < weight.shape[4] <= 8 and x.shape[1] == 1 and x.is_cuda:
         xf = _fold_w(x, weight.shape[4], stride[2], padding)
         wf = weight.permute(0, 4, 2, 3, 1)  # (Cout, KW, KD, KH, 1): autograd maps the gradient back
@@ -425,6 +437,12 @@ def conv3d_linear_pair(x, w_a, b_a, w_b, b_b, padding=0, act="none", slope=0.0):
             bc = bc + w_b.reshape(P, M).float() @ b_a.float()
         if b_b is not None:
             bc = bc + b_b.float()
+    if P == 1 and KH * KW <= 64 and os.environ.get("RAYGUN_AMD_FOLD_HW", "1") != "0":
+        # (kh,kw) -> output channels: a KD-tap conv to KH*KW channels over the padded plane, then the diagonal gather
+        w1 = wc.permute(0, 3, 4, 1, 2).reshape(KH * KW, wc.shape[1], KD, 1, 1)           # channel kh*KW+kw
+        z = conv3d(x, w1, None, 1, padding, "none", 0.0)                                  # H, W extents grow by 2*pad
+        y = _DiagSum.apply(z, KH, KW, 1, z.shape[3] - KH + 1, z.shape[4] - KW + 1, bc)
+        return activation(y, act, slope)
     w1 = wc.permute(0, 4, 1, 2, 3).reshape(P * KW, wc.shape[1], KD, KH, 1)               # channel p*KW+kw <- tap kw
     z = conv3d(x, w1, None, 1, padding, "none", 0.0)                                      # W extent grows by 2*pad_w
     eye = torch.zeros(P, P * KW, 1, 1, KW, dtype=torch.float32, device=w_a.device)
@@ -674,6 +692,49 @@ class _Add(torch.autograd.Function):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+class _DiagSpread(torch.autograd.Function):
+    """y[.,h,w][kh*KW+kw] = x[.,h+s*kh,w+s*kw][0] on an (oh, ow) output grid; adjoint: _DiagSum with -s."""
+
+    @staticmethod
+    def forward(ctx, x, kh, kw, sign, oh, ow):
+        _require_cuda(x, "diag_spread")
+        x = as_cl(x)
+        n, _, d, h, w = x.shape
+        y = cl_empty(n, kh * kw, d, oh, ow, x.device)
+        _lib.check(_lib.lib().rg_diag_spread(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign, _stream()), "rg_diag_spread")
+        ctx.cfg = (kh, kw, sign, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        kh, kw, sign, h, w = ctx.cfg
+        return _DiagSum.apply(g, kh, kw, -sign, h, w, None), None, None, None, None, None
+
+
+class _DiagSum(torch.autograd.Function):
+    """y[.,h,w][0] = bias + sum_{kh,kw} x[.,h+s*kh,w+s*kw][kh*KW+kw] on an (oh, ow) grid; adjoint: _DiagSpread with -s."""
+
+    @staticmethod
+    def forward(ctx, x, kh, kw, sign, oh, ow, bias):
+        _require_cuda(x, "diag_sum")
+        x = as_cl(x)
+        n, _, d, h, w = x.shape
+        y = cl_empty(n, 1, d, oh, ow, x.device)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        _lib.check(_lib.lib().rg_diag_sum(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign,
+                                          C.c_void_p(b.data_ptr()) if b is not None else None, _stream()), "rg_diag_sum")
+        ctx.cfg = (kh, kw, sign, h, w, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        kh, kw, sign, h, w, has_bias = ctx.cfg
+        gb = None
+        if has_bias and ctx.needs_input_grad[6]:
+            gb = _act_bwd_bias(as_cl(g), None, "none", 0.0, True)[1].reshape(1)
+        return _DiagSpread.apply(g, kh, kw, -sign, h, w), None, None, None, None, None, gb
 
 
 def center_crop(x, shape):
