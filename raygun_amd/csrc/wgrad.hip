@@ -652,6 +652,225 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
       }
   }
 }
+// ---- wgrad_kw with producer waves ----------------------------------------------------------------------------------
+// s_memtime stamps on wgrad_kw_kernel<9,9> (one 9-wave workgroup per CU, 168 registers) showed where a step's ~3000 cycles
+// go: ~1100 in the fragment reads + 27 MFMAs, and 1000-1800 in "issuing" three 16-byte loads per thread — at the register
+// cap hipcc recycles/spills the staging registers and waits vmcnt(0) BETWEEN the loads of one step (a memory round trip
+// per step); an LDS-DMA variant (no staging registers) issues at ~57 cycles per 1-KiB piece and serialises the 27 pieces
+// of a step in front of the last wave just the same.  Either way the waves that should feed the MFMA pipe sit in the load
+// path.  So the roles are split: the WA*WB consumer waves only read fragments and issue MFMAs; NPW producer waves (they
+// fill the SIMDs the 9 consumers leave at two waves: 12 waves x 168 registers = the whole file) own the global loads
+// (a third of the tile's pieces each, all in flight at once, loaded one unit ahead of their ds_write) and the LDS stores.
+// One barrier per unit for everybody; LDS image conflict-free for the transposing reads (wg_row).
+constexpr int wg_row(int row, int S) { return row * S + (row >> 3) * 64; }  // every second 8-row group 128 B further: see below
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0) as four SGPR words; dword3 as __builtin_amdgcn_make_buffer_rsrc's 0x00020000
+__device__ __forceinline__ i32x4_t wg_rsrc(const void* base, int nrec) {
+  const unsigned long b = (unsigned long)base;
+  return (i32x4_t){(int)(unsigned)b, (int)((b >> 32) & 0xffffu), nrec, 0x00020000};
+}
+// A buffer load hipcc does not count: the producer waves keep two units of loads in flight ACROSS barriers and retire them
+// with their own counted waits (hipcc's bookkeeping put vmcnt(2..6) waits in front of the next unit's loads).
+__device__ __forceinline__ void wg_load16(u32x4& dst, i32x4_t rsrc, unsigned voff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+template <int N, int P>
+__device__ __forceinline__ void wg_wait_loads(u32x4 (&r)[P]) {  // all but the N youngest loads have landed; names every register of the set
+  static_assert(P == 7, "producer sets hold 7 pieces");
+  asm volatile("s_waitcnt vmcnt(%7)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) : "n"(N) : "memory");
+}
+
+template <int FA, int FB, int WA, int WB, int TWM, int NPW>
+__global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(WgradKwArgs p) {
+  const WgradArgs& a = p.w;
+  constexpr int NC = WA * WB;                 // consumer waves
+  constexpr int TA = FA * 16, TB = FB * 16;
+  constexpr int SA = wg_pad(TA), SB = wg_pad(TB);
+  constexpr int CA = TA / 8, CB = TB / 8;
+  constexpr int XR = 32 + TWM - 1;
+  constexpr int IA = FA / WA, IB = FB / WB;
+  // One ds_read_b64_tr_b16 makes a 32-lane half touch rows {r..r+3} and {r+8..r+11}, 32 bytes each: with a row stride that is
+  // an odd multiple of 32 B the first four tile half a 256-byte bank row, the 128-byte push of every second 8-row group
+  // gives the other four the other half (checked exhaustively for row offsets 0..7; the plain stride is 2-way conflicted
+  // on every fragment read: SQ_LDS_BANK_CONFLICT = 42 % of the LDS cycles of wgrad_kw_kernel).
+  constexpr int GST = wg_row(32, SA), XST = wg_row(XR + 7, SB);
+  // pieces are dealt to the producer waves in 64-piece chunks that are wholly G or wholly X, so that the descriptor of a load
+  // is a wave-uniform choice (a per-lane choice would need both loads and a select on the DATA: an immediate vmcnt wait)
+  constexpr int NGC = (32 * CA + 63) / 64, NXC = (XR * CB + 63) / 64, PER_P = (NGC + NXC + NPW - 1) / NPW;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (GST + XST)];
+  bf16_t* Gs = lds;               // [2][GST]
+  bf16_t* Xs = lds + 2 * GST;     // [2][XST]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int a0, b0, kh, kd, zsplit;
+  {  // XCD-aware logical order: a-tile fastest, then (kd,kh), then b-tile, then split (89 % L2 hits instead of 44 %)
+    const int ny = gridDim.y, total = gridDim.x * ny * gridDim.z;
+    int lin = blockIdx.x + gridDim.x * (blockIdx.y + ny * blockIdx.z);
+    { const int q = total / 8, r = total % 8, xcd = lin % 8, idx = lin / 8; lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int at = lin % p.nta; lin /= p.nta; const int y = lin % ny; lin /= ny; const int bt = lin % p.ntb; zsplit = lin / p.ntb;
+    a0 = at * TA; b0 = bt * TB; kh = y % a.TH; kd = y / a.TH;
+  }
+  const int xrows = 32 + a.TW - 1;
+  const long ubeg = (long)zsplit * p.units_per_split;
+  long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
+  const int ntaps = a.TD * a.TH * a.TW;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b64;
+
+  if (wave >= NC) {
+    // ---------------- producer ----------------
+    const int pw = wave - NC;
+    const int gsw2 = (int)a.gsw * 2, gsh2 = (int)a.gsh * 2, xsw2 = (int)a.xsw * 2;
+    unsigned pv[PER_P]; int pl[PER_P]; int prow[PER_P];  // byte offset at chunk 0 / LDS element offset in stage 0 (X: offset by 2*GST; -1 none) / G row (flat masks)
+#pragma unroll
+    for (int k = 0; k < PER_P; ++k) {
+      const int chunk = pw + NPW * k;  // wave-uniform: chunks [0, NGC) are G pieces, [NGC, NGC + NXC) X pieces
+      pv[k] = WG_OOB; pl[k] = -1; prow[k] = 0;
+      if (chunk < NGC) {
+        const int q = chunk * 64 + lane, row = q / CA, ch = q % CA, c = a0 + ch * 8;
+        if (q < 32 * CA) {
+          pl[k] = wg_row(row, SA) + ch * 8; prow[k] = row;
+          if (c < a.alanes) pv[k] = (unsigned)((p.flat ? 0 : row * gsw2) + c * 2);
+        }
+      } else if (chunk < NGC + NXC) {
+        const int q2 = (chunk - NGC) * 64 + lane, row = q2 / CB, ch = q2 % CB, c = b0 + ch * 8;
+        if (q2 < xrows * CB) {
+          pl[k] = 2 * GST + wg_row(row, SB) + ch * 8;
+          if (c < a.blanes) pv[k] = (unsigned)(row * xsw2 + c * 2);
+        }
+      }
+    }
+    const int rhe = p.flat ? 1 : a.RH;
+    int cwc, crh, crd, cn;
+    {
+      unsigned t = (unsigned)ubeg;
+      cwc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+      crh = (int)(t % (unsigned)rhe); t /= (unsigned)rhe;
+      crd = (int)(t % (unsigned)a.RD); cn = (int)(t / (unsigned)a.RD);
+    }
+    u32x4 regsA[PER_P], regsB[PER_P];  // two units in flight through the registers (memory latency ~ one unit's MFMA time)
+    long gu = ubeg;  // unit under the cursor
+    auto gload = [&](u32x4 (&regs)[PER_P]) {  // unit under the cursor -> registers, then advance
+      const bool live = gu < uend; ++gu;  // past the last unit the loads still issue (counted waits), but read nothing
+      const int w0 = cwc * 32;
+      const int id = crd * a.rs[0] + a.tb[0] + kd * a.ts[0];
+      const bf16_t* gbase; const bf16_t* xbase; int nrecg, nrecx, gadd, xadd;
+      if (p.flat) {
+        const bool ok = (unsigned)id < (unsigned)a.ID;
+        gbase = a.g + cn * a.gsn + crd * a.gsd; nrecg = a.RH * gsh2; gadd = 0;
+        xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd : a.x; nrecx = ok ? a.IH * a.IW * xsw2 : 0;
+        xadd = ((a.tb[1] + kh) * a.IW + a.tb[2] + w0) * xsw2;
+      } else {
+        const int ih = crh * a.rs[1] + a.tb[1] + kh * a.ts[1];
+        const bool ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
+        gbase = a.g + cn * a.gsn + crd * a.gsd + crh * a.gsh; nrecg = a.RW * gsw2; gadd = w0 * gsw2;
+        xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd + (long)ih * a.xsh : a.x; nrecx = ok ? a.IW * xsw2 : 0;
+        xadd = (w0 + a.tb[2]) * xsw2;
+      }
+      const i32x4_t rg = wg_rsrc(live ? gbase : a.g, live ? nrecg : 0), rx = wg_rsrc(live ? xbase : a.x, live ? nrecx : 0);
+#pragma unroll
+      for (int k = 0; k < PER_P; ++k) {
+        const bool isg = pw + NPW * k < NGC;  // wave-uniform
+        unsigned vo = pv[k] + (unsigned)(isg ? gadd : xadd);
+        if (p.flat && isg) {
+          const unsigned o = (unsigned)(w0 + prow[k]), h = __umulhi(o, p.pmagic), w = o - h * (unsigned)a.IW;
+          vo = (w < (unsigned)a.RW && h < (unsigned)a.RH) ? pv[k] + h * (unsigned)gsh2 + w * (unsigned)gsw2 : WG_OOB;
+        }
+        wg_load16(regs[k], isg ? rg : rx, vo);
+      }
+      if (++cwc == p.wchunks) { cwc = 0; if (++crh == rhe) { crh = 0; if (++crd == a.RD) { crd = 0; ++cn; } } }
+    };
+    auto lstore = [&](const u32x4 (&regs)[PER_P], int buf) {
+#pragma unroll
+      for (int k = 0; k < PER_P; ++k) if (pl[k] >= 0) *(u32x4*)(lds + pl[k] + buf * (pl[k] >= 2 * GST ? XST : GST)) = regs[k];
+    };
+    // every gload issues exactly PER_P loads (lanes / chunks with nothing to fetch read out of range), so "all but the
+    // PER_P youngest" retires the older set
+    static_assert(PER_P == 7, "counted waits below assume 7 loads per unit and producer wave");
+    auto pbar = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS stores are done; the loads of later units stay in flight
+      __builtin_amdgcn_s_barrier();                        // unit u is visible to the consumers; the other stage is free
+      asm volatile("" ::: "memory");
+    };
+    gload(regsA); wg_wait_loads<0>(regsA); lstore(regsA, 0);   // unit ubeg (cursor reads past the end are out of range -> zeros)
+    gload(regsA);                                              // unit ubeg+1
+    gload(regsB);                                              // unit ubeg+2
+    for (long u = ubeg; u < uend; u += 2) {
+      pbar();
+      wg_wait_loads<7>(regsA);                                 // unit u+1 landed (unit u+2 may still fly)
+      if (u + 1 < uend && !(p.exp & 16)) lstore(regsA, 1);
+      gload(regsA);                                            // unit u+3
+      if (u + 1 < uend) {
+        pbar();
+        wg_wait_loads<7>(regsB);                               // unit u+2
+        if (u + 2 < uend && !(p.exp & 16)) lstore(regsB, 0);
+        gload(regsB);                                          // unit u+4
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing of mine is in flight when the wave ends
+    return;
+  }
+
+  // ---------------- consumer ----------------
+  const int wa = wave / WB, wb = wave % WB;
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  f32x4 acc[TWM][IA][IB];
+#pragma unroll
+  for (int t = 0; t < TWM; ++t)
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+      for (int j = 0; j < IB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int goff = wg_row(8 * fg + fq, SA) + wa * IA * 16 + 4 * fp;
+  int buf = 0;
+  for (long u = ubeg; u < uend; ++u, buf ^= 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (p.exp & 2) continue;
+    bf16x8 gf[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const bf16_t* base = Gs + buf * GST + goff + i * 16;
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SA));  // rows +4: same 8-row group
+      gf[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int t = 0; t < TWM; ++t) {
+      if (t < a.TW) {
+        const int r0 = t + 8 * fg + fq;
+        const bf16_t* base = Xs + buf * XST + wb * IB * 16 + 4 * fp;
+        const int o_lo = wg_row(r0, SB), o_hi = wg_row(r0 + 4, SB);
+#pragma unroll
+        for (int j = 0; j < IB; ++j) {
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + o_lo + j * 16));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + o_hi + j * 16));
+          const bf16x8 xf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int i = 0; i < IA; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[t][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = a.part + (long)zsplit * a.A * ntaps * a.B;
+#pragma unroll
+  for (int t = 0; t < TWM; ++t) {
+    if (t >= a.TW) continue;
+    const int tap = (kd * a.TH + kh) * a.TW + t;
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+      for (int j = 0; j < IB; ++j) {
+        const int bb = b0 + (wb * IB + j) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int aa = a0 + (wa * IA + i) * 16 + fg * 4 + r;
+          if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[t][i][j][r];
+        }
+      }
+  }
+}
+
 // row order and unit count of the kw-reuse kernel for this problem; false = not eligible
 struct KwGeom { int flat; int wchunks; long units; };
 static bool wgrad_kw_geom(const CL5& G, const CL5& X, const rg_conv_params* p, KwGeom* o) {
@@ -807,7 +1026,10 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
     { const char* e = getenv("RG_EXP"); ka.exp = e ? atoi(e) : 0; }
     dim3 grid(ka.nta * ka.ntb, a.TD * a.TH, ns);
     rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
-    if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
+    if (kind == 1 && !getenv("RG_NO_KWP")) {
+      rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
+      hipLaunchKernelGGL((wgrad_kwp_kernel<9, 9, 3, 3, 3, 3>), grid, dim3(768), 0, st, ka);
+    } else if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
     else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
     else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
     else if (kind == 4) hipLaunchKernelGGL((wgrad_kw_kernel<5, 5, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
