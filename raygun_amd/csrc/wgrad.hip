@@ -676,10 +676,13 @@ __device__ __forceinline__ void wg_load16(u32x4& dst, i32x4_t rsrc, unsigned vof
 }
 template <int N, int P>
 __device__ __forceinline__ void wg_wait_loads(u32x4 (&r)[P]) {  // all but the N youngest loads have landed; names every register of the set
-  static_assert(P == 7, "producer sets hold 7 pieces");
-  asm volatile("s_waitcnt vmcnt(%7)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) : "n"(N) : "memory");
+  static_assert(P >= 4 && P <= 8, "producer sets hold 4..8 pieces");
+  if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N) : "memory");
+  if constexpr (P == 5) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N) : "memory");
+  if constexpr (P == 6) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N) : "memory");
+  if constexpr (P == 7) asm volatile("s_waitcnt vmcnt(%7)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]) : "n"(N) : "memory");
+  if constexpr (P == 8) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
 }
-
 template <int FA, int FB, int WA, int WB, int TWM, int NPW>
 __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(WgradKwArgs p) {
   const WgradArgs& a = p.w;
@@ -785,7 +788,6 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
     };
     // every gload issues exactly PER_P loads (lanes / chunks with nothing to fetch read out of range), so "all but the
     // PER_P youngest" retires the older set
-    static_assert(PER_P == 7, "counted waits below assume 7 loads per unit and producer wave");
     auto pbar = [&]() {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS stores are done; the loads of later units stay in flight
       __builtin_amdgcn_s_barrier();                        // unit u is visible to the consumers; the other stage is free
@@ -796,12 +798,12 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
     gload(regsB);                                              // unit ubeg+2
     for (long u = ubeg; u < uend; u += 2) {
       pbar();
-      wg_wait_loads<7>(regsA);                                 // unit u+1 landed (unit u+2 may still fly)
+      wg_wait_loads<PER_P>(regsA);                             // unit u+1 landed (unit u+2 may still fly)
       if (u + 1 < uend && !(p.exp & 16)) lstore(regsA, 1);
       gload(regsA);                                            // unit u+3
       if (u + 1 < uend) {
         pbar();
-        wg_wait_loads<7>(regsB);                               // unit u+2
+        wg_wait_loads<PER_P>(regsB);                           // unit u+2
         if (u + 2 < uend && !(p.exp & 16)) lstore(regsB, 0);
         gload(regsB);                                          // unit u+4
       }
@@ -1031,7 +1033,10 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
       hipLaunchKernelGGL((wgrad_kwp_kernel<9, 9, 3, 3, 3, 3>), grid, dim3(768), 0, st, ka);
     } else if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
     else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
-    else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
+    else if (kind == 3 && a.TW <= 3 && !getenv("RG_NO_KWP")) {
+      rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
+      hipLaunchKernelGGL((wgrad_kwp_kernel<8, 8, 2, 4, 3, 4>), grid, dim3(768), 0, st, ka);
+    } else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
     else if (kind == 4) hipLaunchKernelGGL((wgrad_kw_kernel<5, 5, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
     else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
