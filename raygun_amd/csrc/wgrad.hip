@@ -1037,6 +1037,7 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
       rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
       hipLaunchKernelGGL((wgrad_kwp_kernel<8, 8, 2, 4, 3, 4>), grid, dim3(768), 0, st, ka);
     } else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
+    else if (kind == 4 && !getenv("RG_NO_KWP")) { rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb); hipLaunchKernelGGL((wgrad_kwp_kernel<5, 5, 5, 1, 3, 3>), grid, dim3(512), 0, st, ka); }
     else if (kind == 4) hipLaunchKernelGGL((wgrad_kw_kernel<5, 5, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
     else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
