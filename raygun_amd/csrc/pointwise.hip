@@ -34,19 +34,50 @@ __device__ __forceinline__ float load_any(const AnyT& t, long off) {
 __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int H, int W, int lanes, float scale, float shift) {
   const int G8 = (lanes + 7) / 8;
   const long nvox = (long)N * D * H * W, total = nvox * G8;
+  // the channels-last side (bf16, channel stride 1, 16-byte voxel granules) moves as ONE 16-byte access per thread; the dense
+  // side stays one element per lane and channel (consecutive threads = consecutive voxels: coalesced)
+  const bool dst_cl = dst.dtype == RG_BF16 && dst.s[1] == 1 && (lanes & 7) == 0;
+  const bool src_cl = src.dtype == RG_BF16 && src.s[1] == 1 && ((C + 7) / 8 * 8) <= lanes;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long v = i % nvox; const int grp = (int)(i / nvox);
-    long t = v;
-    const int w = (int)(t % W); t /= W; const int h = (int)(t % H); t /= H; const int d = (int)(t % D); const int n = (int)(t / D);
-    const long so = n * src.s[0] + d * src.s[2] + h * src.s[3] + w * src.s[4];
-    const long dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
+    long so, dof;
+    if (nvox < (1L << 31)) {  // 32-bit index arithmetic (the common case)
+      unsigned t = (unsigned)v;
+      const unsigned w = t % (unsigned)W; t /= (unsigned)W; const unsigned h = t % (unsigned)H; t /= (unsigned)H;
+      const unsigned d = t % (unsigned)D; const unsigned n = t / (unsigned)D;
+      so = n * src.s[0] + d * src.s[2] + h * src.s[3] + w * src.s[4];
+      dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
+    } else {
+      long t = v;
+      const int w = (int)(t % W); t /= W; const int h = (int)(t % H); t /= H; const int d = (int)(t % D); const int n = (int)(t / D);
+      so = n * src.s[0] + d * src.s[2] + h * src.s[3] + w * src.s[4];
+      dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
+    }
+    float val[8];
+    if (src_cl && grp * 8 + 8 <= ((C + 7) / 8 * 8)) {
+      const bf16x8 raw = *(const bf16x8*)((const bf16_t*)src.p + so + grp * 8);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = grp * 8 + k;
-      if (c >= lanes) break;
-      const float val = c < C ? load_any(src, so + c * src.s[1]) * scale + shift : 0.f;
-      if (dst.dtype == RG_F32) ((float*)dst.p)[dof + c * dst.s[1]] = val;
-      else ((bf16_t*)dst.p)[dof + c * dst.s[1]] = f2bf(val);
+      for (int k = 0; k < 8; ++k) val[k] = grp * 8 + k < C ? bf2f((bf16_t)raw[k]) * scale + shift : 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = grp * 8 + k;
+        val[k] = c < C ? load_any(src, so + c * src.s[1]) * scale + shift : 0.f;
+      }
+    }
+    if (dst_cl) {
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (short)f2bf(val[k]);
+      *(bf16x8*)((bf16_t*)dst.p + dof + grp * 8) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = grp * 8 + k;
+        if (c >= lanes) break;
+        if (dst.dtype == RG_F32) ((float*)dst.p)[dof + c * dst.s[1]] = val[k];
+        else ((bf16_t*)dst.p)[dof + c * dst.s[1]] = f2bf(val[k]);
+      }
     }
   }
 }
