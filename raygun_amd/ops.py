@@ -58,6 +58,13 @@ def cl_empty(n, c, d, h, w, device):
     return buf.permute(0, 4, 1, 2, 3)[:, :c]
 
 
+def cl_empty_dw(n, c, d, h, w, device):
+    """(N,C,D,H,W) channels-last view whose memory is laid out with D and W exchanged: what `t.transpose(2, 4)` of an ordinary
+    channels-last tensor of shape (N,C,W,H,D) looks like.  Outputs of the D<->W-swapped convolutions below are allocated
+    this way so that, swapped back, they are ordinary channels-last tensors again."""
+    return cl_empty(n, c, w, h, d, device).transpose(2, 4)
+
+
 def is_cl(t):
     if t.dtype != torch.bfloat16 or t.dim() != 5 or not t.is_cuda:
         return False
@@ -330,9 +337,13 @@ class _Conv3d(torch.autograd.Function):
     networks/ResNet.py:283,291-298,337-338,407,416, networks/NLayerDiscriminator.py:136-176."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act, slope):
+    def forward(ctx, x, weight, bias, stride, padding, act, slope, dw_swapped=False):
+        """dw_swapped: x (and gy) are D<->W transposed views of ordinary channels-last tensors (conv_kd_as_kw); outputs are
+        allocated so that they are ordinary again once swapped back."""
         _require_cuda(x, "conv3d")
         x = as_cl(x)
+        alloc = cl_empty_dw if dw_swapped else cl_empty
+        ctx.alloc = alloc
         n, cin, D, H, W = x.shape
         cout, cin_w = weight.shape[0], weight.shape[1]
         K = tuple(weight.shape[2:])
@@ -343,7 +354,7 @@ class _Conv3d(torch.autograd.Function):
         if min(O) <= 0:
             raise RuntimeError(f"Calculated padded input size per channel: {tuple(i + 2 * p for i, p in zip((D, H, W), padding))}. "
                                f"Kernel size: {K}. Kernel size can't be greater than actual input size")
-        y = cl_empty(n, cout, *O, x.device)
+        y = alloc(n, cout, *O, x.device)
         wp = pack_weights(weight, swap=0)
         b = bias.detach().float().contiguous() if bias is not None else None
         p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
@@ -362,7 +373,7 @@ class _Conv3d(torch.autograd.Function):
         gx = dw = None
         n, cin, D, H, W = x.shape
         if ctx.needs_input_grad[0]:
-            gx = cl_empty(n, cin, D, H, W, x.device)
+            gx = ctx.alloc(n, cin, D, H, W, x.device)
             if stride == (1, 1, 1):
                 wp = pack_weights(weight, swap=1)
                 p = _conv_params(R=(D, H, W), T=K, rstride=(1, 1, 1), tbase=padding, tstep=(-1, -1, -1),
@@ -376,7 +387,16 @@ class _Conv3d(torch.autograd.Function):
             dw = _wgrad(g, x, p, weight.shape).to(weight.dtype)
         if db is not None:
             db = db.to(weight.dtype)
-        return gx, dw, db, None, None, None, None
+        return gx, dw, db, None, None, None, None, None
+
+
+def conv_kd_as_kw(x, weight, bias, act="none", slope=0.0):
+    """A stride-1, unpadded convolution whose kernel only extends along D — (KD,1,1), what is left of a 7^3 stem / tail once
+    its in-plane taps are folded into channels — run with D and W exchanged: the kernels reuse staged tiles across the taps
+    of the INNERMOST axis only (igemm3, wgrad_kw: 700+ TFLOP/s instead of 130-270 on a (7,1,1) kernel), and they take every
+    spatial stride as a parameter, so the exchange is two zero-copy views."""
+    y = _Conv3d.apply(enter(x).transpose(2, 4), weight.transpose(2, 4), bias, (1, 1, 1), (0, 0, 0), act, float(slope), True)
+    return y.transpose(2, 4)
 
 
 def _fold_w(x, kw, stride_w, pad):
@@ -406,7 +426,7 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
         kd, kh, kw = weight.shape[2:]
         xf = _DiagSpread.apply(x, kh, kw, 1, x.shape[3] - kh + 1, x.shape[4] - kw + 1)
         wf = weight.permute(0, 3, 4, 2, 1).reshape(weight.shape[0], kh * kw, kd, 1, 1)  # [cout][(kh,kw)][kd]
-        return _Conv3d.apply(xf, wf, bias, (1, 1, 1), (0, 0, 0), act, float(slope))
+        return conv_kd_as_kw(xf, wf, bias, act, slope)
     if weight.shape[1] == 1 and 1 < weight.shape[4] <= 8 and x.shape[1] == 1 and x.is_cuda:
         xf = _fold_w(x, weight.shape[4], stride[2], padding)
         wf = weight.permute(0, 4, 2, 3, 1)  # (Cout, KW, KD, KH, 1): autograd maps the gradient back
@@ -440,7 +460,10 @@ def conv3d_linear_pair(x, w_a, b_a, w_b, b_b, padding=0, act="none", slope=0.0):
     if P == 1 and KH * KW <= 64 and os.environ.get("RAYGUN_AMD_FOLD_HW", "1") != "0":
         # (kh,kw) -> output channels: a KD-tap conv to KH*KW channels over the padded plane, then the diagonal gather
         w1 = wc.permute(0, 3, 4, 1, 2).reshape(KH * KW, wc.shape[1], KD, 1, 1)           # channel kh*KW+kw
-        z = conv3d(x, w1, None, 1, padding, "none", 0.0)                                  # H, W extents grow by 2*pad
+        x = enter(x)
+        if any(padding):
+            x = pad3d(x, padding, "zeros")                                                # H, W extents grow by 2*pad
+        z = conv_kd_as_kw(x, w1, None)
         y = _DiagSum.apply(z, KH, KW, 1, z.shape[3] - KH + 1, z.shape[4] - KW + 1, bc)
         return activation(y, act, slope)
     w1 = wc.permute(0, 4, 1, 2, 3).reshape(P * KW, wc.shape[1], KD, KH, 1)               # channel p*KW+kw <- tap kw
