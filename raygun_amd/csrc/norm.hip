@@ -26,9 +26,18 @@ extern "C" int64_t rg_instnorm_workspace_bytes(const rg_tensor* x) {
   return (int64_t)t.N * p.nblk * t.lanes * 2 * 4;
 }
 
+// Thread (tx, ty) of block (bx, by, n): channel group by*GX + tx (its 8 (mean, rstd) pairs are loaded ONCE), voxels
+// bx*vpb + ty, + GY, ...  Voxel offsets are v * voxel stride when every tensor is dense in D,H,W (no per-element
+// divisions); the strided path decodes (d,h,w) with 32-bit divisions.
+__device__ __forceinline__ long vox_off(const CL5& t, int n, unsigned v, bool dense) {
+  if (dense) return n * t.sn + (long)v * t.sw;
+  const unsigned w = v % (unsigned)t.W; v /= (unsigned)t.W; const unsigned h = v % (unsigned)t.H; const unsigned d = v / (unsigned)t.H;
+  return n * t.sn + d * t.sd + h * t.sh + w * t.sw;
+}
+static bool cl_dense(const CL5& t) { return t.sh == (long)t.W * t.sw && t.sd == (long)t.H * t.sh; }
 // MODE 0: s0 = sum x, s1 = sum x^2.   MODE 1 (backward): g = gy*act'(y); s0 = sum g, s1 = sum g*xhat
 template <int MODE>
-__global__ void norm_reduce_kernel(CL5 x, CL5 y, CL5 gy, const float* mr, float* partial, int vpb, int act, float slope) {
+__global__ void norm_reduce_kernel(CL5 x, CL5 y, CL5 gy, const float* mr, float* partial, int vpb, int act, float slope, int dense) {
   extern __shared__ float red[];  // [GY][GX][16]
   const int GX = blockDim.x, GY = blockDim.y;
   const int grp = blockIdx.y * GX + threadIdx.x;
@@ -48,16 +57,14 @@ __global__ void norm_reduce_kernel(CL5 x, CL5 y, CL5 gy, const float* mr, float*
   }
   if (active) {
     for (long v = v0 + threadIdx.y; v < v1; v += GY) {
-      long t = v;
-      const int w = (int)(t % x.W); t /= x.W; const int h = (int)(t % x.H); const int d = (int)(t / x.H);
-      const bf16x8 xv = *(const bf16x8*)(x.p + n * x.sn + d * x.sd + h * x.sh + w * x.sw + grp * 8);
+      const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, (unsigned)v, dense) + grp * 8);
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const float f = bf2f((bf16_t)xv[k]); s0[k] += f; s1[k] += f * f; }
       } else {
-        const bf16x8 gv = *(const bf16x8*)(gy.p + n * gy.sn + d * gy.sd + h * gy.sh + w * gy.sw + grp * 8);
+        const bf16x8 gv = *(const bf16x8*)(gy.p + vox_off(gy, n, (unsigned)v, dense) + grp * 8);
         bf16x8 yv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
+        if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + vox_off(y, n, (unsigned)v, dense) + grp * 8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float g = bf2f((bf16_t)gv[k]) * act_bwd_from_y(bf2f((bf16_t)yv[k]), act, slope);
@@ -103,7 +110,7 @@ extern "C" int rg_instnorm_stats(const rg_tensor* x, float* mean_rstd, float eps
   const size_t need = (size_t)X.N * p.nblk * X.lanes * 2 * 4;
   if (!workspace || ws_bytes < need || !mean_rstd) RG_FAIL(RG_ERR_WORKSPACE, "instnorm_stats: workspace %zu < %zu", ws_bytes, need);
   dim3 grid(p.nblk, (X.lanes / 8 + p.gx - 1) / p.gx, X.N), block(p.gx, p.gy);
-  hipLaunchKernelGGL((norm_reduce_kernel<0>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, X, X, (const float*)nullptr, (float*)workspace, p.vpb, 0, 0.f);
+  hipLaunchKernelGGL((norm_reduce_kernel<0>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, X, X, (const float*)nullptr, (float*)workspace, p.vpb, 0, 0.f, (int)cl_dense(X));
   RG_CHECK_LAUNCH();
   hipLaunchKernelGGL((norm_finalize_kernel<0>), dim3(X.N * X.C), dim3(64), 0, (hipStream_t)s, (const float*)workspace, mean_rstd, X.N, X.C, X.lanes, p.nblk,
                      (long)X.D * X.H * X.W, eps);
@@ -111,28 +118,41 @@ extern "C" int rg_instnorm_stats(const rg_tensor* x, float* mean_rstd, float eps
   return RG_OK;
 }
 
-__global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, int act, float slope, int has_res) {
-  const int G8 = y.lanes / 8;
-  const long total = (long)y.N * y.D * y.H * y.W * G8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int grp = (int)(i % G8); long t = i / G8;
-    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
-    const bf16x8 xv = *(const bf16x8*)(x.p + n * x.sn + d * x.sd + h * x.sh + w * x.sw + grp * 8);
+__global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, int act, float slope, int has_res, int vpb, int dense) {
+  const int grp = blockIdx.y * blockDim.x + threadIdx.x, n = blockIdx.z;
+  if (grp * 8 >= y.lanes) return;
+  float m[8], r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = grp * 8 + k;
+    m[k] = c < x.C ? mr[((long)n * x.C + c) * 2] : 0.f; r[k] = c < x.C ? mr[((long)n * x.C + c) * 2 + 1] : 0.f;
+  }
+  const unsigned nvox = (unsigned)(y.D * y.H * y.W);
+  const unsigned v0 = blockIdx.x * (unsigned)vpb;
+  unsigned v1 = v0 + (unsigned)vpb; if (v1 > nvox) v1 = nvox;
+  for (unsigned v = v0 + threadIdx.y; v < v1; v += blockDim.y) {
+    const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
     bf16x8 rv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (has_res) rv = *(const bf16x8*)(res.p + n * res.sn + d * res.sd + h * res.sh + w * res.sw + grp * 8);
+    if (has_res) rv = *(const bf16x8*)(res.p + vox_off(res, n, v, dense) + grp * 8);
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int c = grp * 8 + k;
-      float v = 0.f;
-      if (c < x.C) {
-        const float m = mr[((long)n * x.C + c) * 2], r = mr[((long)n * x.C + c) * 2 + 1];
-        v = act_fwd((bf2f((bf16_t)xv[k]) - m) * r, act, slope) + bf2f((bf16_t)rv[k]);
-      }
-      o[k] = (short)f2bf(v);
+      float val = 0.f;
+      if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[k]) - m[k]) * r[k], act, slope) + bf2f((bf16_t)rv[k]);
+      o[k] = (short)f2bf(val);
     }
-    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8) = o;
+    *(bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8) = o;
   }
+}
+// launch shape shared by apply / bwd: ~2048 workgroups of (gx channel groups) x (256/gx voxels in flight)
+static void norm_ew_plan(const CL5& t, dim3* grid, dim3* block, int* vpb) {
+  const int G8 = t.lanes / 8;
+  int gx = 1; while (gx < G8 && gx < 32) gx <<= 1;
+  const int gy = 256 / gx, ngy = (G8 + gx - 1) / gx;
+  const long nvox = (long)t.D * t.H * t.W;
+  long want = 2048 / ((long)ngy * t.N); if (want < 1) want = 1;
+  long v = (nvox + want - 1) / want; if (v < gy * 4) v = gy * 4;
+  *vpb = (int)v; *grid = dim3((unsigned)((nvox + v - 1) / v), ngy, t.N); *block = dim3(gx, gy);
 }
 static bool same_shape(const CL5& a, const CL5& b) { return a.N == b.N && a.C == b.C && a.D == b.D && a.H == b.H && a.W == b.W; }
 
@@ -144,37 +164,45 @@ extern "C" int rg_instnorm_apply(const rg_tensor* x, const float* mean_rstd, con
   const int has_res = res && res->ptr;
   if (has_res) { if ((rc = rg_as_cl5(res, &R, "instnorm.res"))) return rc; if (!same_shape(R, X)) RG_FAIL(RG_ERR_BAD_SHAPE, "instnorm_apply: residual shape mismatch"); }
   if (!same_shape(X, Y) || !mean_rstd) RG_FAIL(RG_ERR_BAD_SHAPE, "instnorm_apply: shape mismatch / null stats");
-  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
-  hipLaunchKernelGGL(norm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, R, Y, mean_rstd, act, slope, has_res);
+  if ((long)Y.D * Y.H * Y.W >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "instnorm_apply: more than 2^31 voxels per sample");
+  dim3 grid, block; int vpb;
+  norm_ew_plan(Y, &grid, &block, &vpb);
+  const int dense = cl_dense(X) && cl_dense(Y) && (!has_res || cl_dense(R));
+  hipLaunchKernelGGL(norm_apply_kernel, grid, block, 0, (hipStream_t)s, X, R, Y, mean_rstd, act, slope, has_res, vpb, dense);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
 
-__global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, const float* gm, int act, float slope) {
-  const int G8 = gx.lanes / 8;
-  const long total = (long)gx.N * gx.D * gx.H * gx.W * G8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int grp = (int)(i % G8); long t = i / G8;
-    const int w = (int)(t % gx.W); t /= gx.W; const int h = (int)(t % gx.H); t /= gx.H; const int d = (int)(t % gx.D); const int n = (int)(t / gx.D);
-    const bf16x8 xv = *(const bf16x8*)(x.p + n * x.sn + d * x.sd + h * x.sh + w * x.sw + grp * 8);
-    const bf16x8 gv = *(const bf16x8*)(gy.p + n * gy.sn + d * gy.sd + h * gy.sh + w * gy.sw + grp * 8);
+__global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, const float* gm, int act, float slope, int vpb, int dense) {
+  const int grp = blockIdx.y * blockDim.x + threadIdx.x, n = blockIdx.z;
+  if (grp * 8 >= gx.lanes) return;
+  float m[8], r[8], g0[8], g1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = grp * 8 + k;
+    const long q = ((long)n * x.C + (c < x.C ? c : 0)) * 2;
+    m[k] = mr[q]; r[k] = mr[q + 1]; g0[k] = gm[q]; g1[k] = gm[q + 1];
+  }
+  const unsigned nvox = (unsigned)(gx.D * gx.H * gx.W);
+  const unsigned v0 = blockIdx.x * (unsigned)vpb;
+  unsigned v1 = v0 + (unsigned)vpb; if (v1 > nvox) v1 = nvox;
+  for (unsigned v = v0 + threadIdx.y; v < v1; v += blockDim.y) {
+    const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
+    const bf16x8 gv = *(const bf16x8*)(gy.p + vox_off(gy, n, v, dense) + grp * 8);
     bf16x8 yv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
+    if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8);
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int c = grp * 8 + k;
-      float v = 0.f;
-      if (c < x.C) {
-        const long q = ((long)n * x.C + c) * 2;
-        const float m = mr[q], r = mr[q + 1];
+      float val = 0.f;
+      if (grp * 8 + k < x.C) {
         const float g = bf2f((bf16_t)gv[k]) * act_bwd_from_y(bf2f((bf16_t)yv[k]), act, slope);
-        const float xh = (bf2f((bf16_t)xv[k]) - m) * r;
-        v = r * (g - gm[q] - xh * gm[q + 1]);
+        const float xh = (bf2f((bf16_t)xv[k]) - m[k]) * r[k];
+        val = r[k] * (g - g0[k] - xh * g1[k]);
       }
-      o[k] = (short)f2bf(v);
+      o[k] = (short)f2bf(val);
     }
-    *(bf16x8*)(gx.p + n * gx.sn + d * gx.sd + h * gx.sh + w * gx.sw + grp * 8) = o;
+    *(bf16x8*)(gx.p + vox_off(gx, n, v, dense) + grp * 8) = o;
   }
 }
 extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const rg_tensor* y, const rg_tensor* gy,
@@ -189,13 +217,16 @@ extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const
   if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "instnorm_bwd: workspace %zu < %zu (use rg_instnorm_workspace_bytes + N*C*8)", ws_bytes, need);
   float* gm = (float*)((char*)workspace + part);
   dim3 grid(p.nblk, (X.lanes / 8 + p.gx - 1) / p.gx, X.N), block(p.gx, p.gy);
-  hipLaunchKernelGGL((norm_reduce_kernel<1>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, Y, GY, mean_rstd, (float*)workspace, p.vpb, act, slope);
+  hipLaunchKernelGGL((norm_reduce_kernel<1>), grid, block, 256 * 16 * sizeof(float), (hipStream_t)s, X, Y, GY, mean_rstd, (float*)workspace, p.vpb, act, slope, (int)(cl_dense(X) && cl_dense(GY) && (act == RG_ACT_NONE || cl_dense(Y))));
   RG_CHECK_LAUNCH();
   hipLaunchKernelGGL((norm_finalize_kernel<1>), dim3(X.N * X.C), dim3(64), 0, (hipStream_t)s, (const float*)workspace, gm, X.N, X.C, X.lanes, p.nblk,
                      (long)X.D * X.H * X.W, 0.f);
   RG_CHECK_LAUNCH();
-  const long total = (long)GX.N * GX.D * GX.H * GX.W * (GX.lanes / 8);
-  hipLaunchKernelGGL(norm_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, GY, GX, mean_rstd, (const float*)gm, act, slope);
+  if ((long)GX.D * GX.H * GX.W >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "instnorm_bwd: more than 2^31 voxels per sample");
+  dim3 egrid, eblock; int evpb;
+  norm_ew_plan(GX, &egrid, &eblock, &evpb);
+  const int dense = cl_dense(X) && cl_dense(GY) && cl_dense(GX) && (act == RG_ACT_NONE || cl_dense(Y));
+  hipLaunchKernelGGL(norm_bwd_kernel, egrid, eblock, 0, (hipStream_t)s, X, Y, GY, GX, mean_rstd, (const float*)gm, act, slope, evpb, dense);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
