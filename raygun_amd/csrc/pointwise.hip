@@ -526,25 +526,38 @@ __global__ void diag_spread_kernel(CL5 x, CL5 y, int KH, int KW, int sgn) {
     *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + g * 8) = o;
   }
 }
-__global__ void diag_sum_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, const float* bias) {
-  const long nvox = (long)y.N * y.D * y.H * y.W;
-  const float b = bias ? bias[0] : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (long)gridDim.x * blockDim.x) {
-    long t = i;
-    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
-    float acc = b;
-    for (int kh = 0; kh < KH; ++kh) {
-      const int hh = h + sgn * kh;
-      if ((unsigned)hh >= (unsigned)x.H) continue;
-      for (int kw = 0; kw < KW; ++kw) {
-        const int ww = w + sgn * kw;
-        if ((unsigned)ww < (unsigned)x.W) acc += bf2f(x.p[n * x.sn + d * x.sd + hh * x.sh + ww * x.sw + kh * KW + kw]);
-      }
-    }
-    bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    o[0] = (short)f2bf(acc);
-    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw) = o;
+// One workgroup per (n, d, DS_TH x DS_TW output tile): the (DS_TH+KH-1) x (DS_TW+KW-1) input voxel records are staged in LDS
+// with coalesced 16-byte loads (a thread-per-output gather of 2-byte lanes from KH*KW different records ran at 1.2 ms for
+// the 49-channel 128x134x134 tail tensor), then every thread sums its KH*KW diagonal entries.  LDS voxel stride 72 lanes
+// (144 B): 16 consecutive voxels start in 16 different banks.
+#define DS_TH 4
+#define DS_TW 32
+#define DS_LS 72
+__global__ __launch_bounds__(128) void diag_sum_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, const float* bias, int tiles_w, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t dtile[];
+  const int RW = DS_TW + KW - 1, RH = DS_TH + KH - 1, G8 = x.lanes / 8;
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w; const int th = b % tiles_h; b /= tiles_h; const int d = b % y.D; const int n = b / y.D;
+  const int h0 = th * DS_TH, w0 = tw * DS_TW;
+  const int ih0 = sgn > 0 ? h0 : h0 - (KH - 1), iw0 = sgn > 0 ? w0 : w0 - (KW - 1);
+  for (int i = threadIdx.x; i < RH * RW * G8; i += blockDim.x) {
+    const int g = i % G8, v = i / G8, c = v % RW, r = v / RW;
+    const int hh = ih0 + r, ww = iw0 + c;
+    bf16x8 val = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) val = *(const bf16x8*)(x.p + n * x.sn + d * x.sd + hh * x.sh + ww * x.sw + g * 8);
+    *(bf16x8*)(dtile + (r * RW + c) * DS_LS + g * 8) = val;
   }
+  __syncthreads();
+  const int lh = threadIdx.x / DS_TW, lw = threadIdx.x % DS_TW;
+  const int h = h0 + lh, w = w0 + lw;
+  if (h >= y.H || w >= y.W) return;
+  float acc = bias ? bias[0] : 0.f;
+  const int rb = sgn > 0 ? lh : lh + KH - 1, cb = sgn > 0 ? lw : lw + KW - 1;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) acc += bf2f(dtile[((rb + sgn * kh) * RW + cb + sgn * kw) * DS_LS + kh * KW + kw]);
+  bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  o[0] = (short)f2bf(acc);
+  *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw) = o;
 }
 static int diag_check(const rg_tensor* one, const rg_tensor* many, CL5* O, CL5* M, int KH, int KW, const char* what) {
   int rc;
@@ -566,8 +579,13 @@ extern "C" int rg_diag_spread(const rg_tensor* x, const rg_tensor* y, int kh, in
 extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, const float* bias, rg_stream s) {
   CL5 X, Y; int rc;
   if ((rc = diag_check(y, x, &Y, &X, kh, kw, "diag_sum"))) return rc;
-  const long total = (long)Y.N * Y.D * Y.H * Y.W;
-  hipLaunchKernelGGL(diag_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias);
+  if (X.lanes > DS_LS) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: more than %d channel lanes", DS_LS);
+  const int tiles_w = (Y.W + DS_TW - 1) / DS_TW, tiles_h = (Y.H + DS_TH - 1) / DS_TH;
+  const size_t shm = (size_t)(DS_TH + kh - 1) * (DS_TW + kw - 1) * DS_LS * 2;
+  if (shm > 64 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: %dx%d taps need %zu bytes of LDS", kh, kw, shm);
+  const long nblk = (long)Y.N * Y.D * tiles_h * tiles_w;
+  if (nblk >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: grid too large");
+  hipLaunchKernelGGL(diag_sum_kernel, dim3((unsigned)nblk), dim3(DS_TH * DS_TW), shm, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias, tiles_w, tiles_h);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
