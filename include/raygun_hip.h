@@ -66,6 +66,7 @@ typedef struct {
   int32_t swap;
   int32_t k0[3], kstep[3], ntap[3];
   int32_t red_align; /* = rg_conv3d_kalign(reduced, rows): 64/32/8 = reduced-channel padding per tap, 1 = FLAT rows; 0 means 32 */
+  int32_t src_channels_last; /* 0: w is (dim0, dim1, KD,KH,KW) contiguous; 1: torch.channels_last_3d memory, i.e. [dim0][KD][KH][KW][dim1] */
 } rg_pack_params;
 /* Packing mode (rg_pack_params.red_align) that rg_conv3d_igemm expects for a problem with `cin` reduced and `cout` produced channels */
 int rg_conv3d_kalign(int cin, int cout);
@@ -98,6 +99,10 @@ int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias,
 int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_tensor* x, const rg_conv_params* p, int32_t* nsplit);
 int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int accumulate,
                     void* workspace, size_t ws_bytes, rg_stream s);
+/* flags bit 0: accumulate; bit 1: dw is channels-last memory, [a][KD][KH][KW][b] (torch.channels_last_3d of an (a,b,KD,KH,KW)
+ * tensor) — the layout the kernels accumulate in: with one row split the partial sums ARE the result (no transpose pass). */
+int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int flags,
+                     void* workspace, size_t ws_bytes, rg_stream s);
 
 /* ---- activation backward + bias gradient: g = gy * act'(y);  db[c] = sum_voxels g  (fp32, may be NULL).
  * Replaces autograd of ReLU/LeakyReLU/Sigmoid after a conv (UNet.py:90-91, NLayerDiscriminator.py:138,156,173). */

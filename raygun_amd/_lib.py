@@ -21,7 +21,7 @@ class rg_tensor(C.Structure):
 
 class rg_pack_params(C.Structure):
     _fields_ = [("dim0", C.c_int32), ("dim1", C.c_int32), ("K", C.c_int32 * 3), ("swap", C.c_int32),
-                ("k0", C.c_int32 * 3), ("kstep", C.c_int32 * 3), ("ntap", C.c_int32 * 3), ("red_align", C.c_int32)]
+                ("k0", C.c_int32 * 3), ("kstep", C.c_int32 * 3), ("ntap", C.c_int32 * 3), ("red_align", C.c_int32), ("src_channels_last", C.c_int32)]
 
 
 class rg_conv_params(C.Structure):
@@ -48,6 +48,7 @@ _SIGS = {
     "rg_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
     "rg_conv3d_igemm": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p]),
     "rg_conv3d_wgrad_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params), _P(C.c_int32)]),
+    "rg_conv3d_wgrad2": (C.c_int, [_T, _T, C.c_void_p, _P(rg_conv_params), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_conv3d_wgrad": (C.c_int, [_T, _T, C.c_void_p, _P(rg_conv_params), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_act_bwd_bias": (C.c_int, [_T, _T, _T, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_act_bwd_bias_workspace_bytes": (C.c_int64, [_T]),

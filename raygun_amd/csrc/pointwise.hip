@@ -153,6 +153,51 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, bf16_
     __syncthreads();
   }
 }
+// Source in channels-last memory [dim0][source tap][dim1] (torch.channels_last_3d master weights: the layout the
+// weight-gradient kernels produce and Adam therefore updates in).
+//  swap 0 (rows = dim0, reduced = dim1): every (row, tap) is one contiguous run of dim1 floats -> convert + pad, 8 per thread.
+//  swap 1 (rows = dim1, reduced = dim0): a dim0 x dim1 transpose per tap, 64x64 tiles through LDS (256-B reads, 128-B writes).
+__device__ __forceinline__ int pk_src_tap(const rg_pack_params& p, int tap) {
+  const int jw = tap % p.ntap[2], jh = (tap / p.ntap[2]) % p.ntap[1], jd = tap / (p.ntap[2] * p.ntap[1]);
+  return ((p.k0[0] + p.kstep[0] * jd) * p.K[1] + p.k0[1] + p.kstep[1] * jh) * p.K[2] + p.k0[2] + p.kstep[2] * jw;
+}
+__global__ __launch_bounds__(256) void pack_cl_rows_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32, long rowlen) {
+  const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2], kvol = p.K[0] * p.K[1] * p.K[2], ng = red32 / 8;
+  const long total = (long)rows16 * ntap * ng;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int g = (int)(i % ng); long t = i / ng; const int tap = (int)(t % ntap); const int row = (int)(t / ntap);
+    bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < rows) {
+      const float* src = w + ((long)row * kvol + pk_src_tap(p, tap)) * p.dim1 + g * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (g * 8 + k < red) o[k] = (short)f2bf(src[k]);
+    }
+    *(bf16x8*)(out + (long)row * rowlen + (long)tap * red32 + g * 8) = o;
+  }
+}
+__global__ __launch_bounds__(256) void pack_cl_transpose_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32, long rowlen) {
+  __shared__ float tile[64][65];  // [k (dim0)][r (dim1)]
+  const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2], kvol = p.K[0] * p.K[1] * p.K[2];
+  const int nkt = (red32 + 63) / 64, nrt = (rows16 + 63) / 64;
+  int b = blockIdx.x;
+  const int kt = b % nkt; b /= nkt; const int rt = b % nrt; const int tap = b / nrt;
+  const int k0 = kt * 64, r0 = rt * 64, st = pk_src_tap(p, tap);
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int kk = i >> 6, rr = i & 63;
+    float v = 0.f;
+    if (k0 + kk < red && r0 + rr < rows) v = w[((long)(k0 + kk) * kvol + st) * p.dim1 + r0 + rr];
+    tile[kk][rr] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+    const int rr = i >> 3, g = i & 7;
+    if (r0 + rr >= rows16 || k0 + g * 8 >= red32) continue;
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (short)f2bf(tile[g * 8 + q][rr]);
+    *(bf16x8*)(out + (long)(r0 + rr) * rowlen + (long)tap * red32 + k0 + g * 8) = o;
+  }
+}
 static int pack_align(const rg_pack_params* p) { return p->red_align == 64 ? 64 : ((p->red_align == 8 || p->red_align == 1) ? 8 : 32); }
 static long pack_rowlen(const rg_pack_params* p, int red) {
   const long n = (long)p->ntap[0] * p->ntap[1] * p->ntap[2] * round_up(red, pack_align(p));
@@ -179,6 +224,22 @@ extern "C" int rg_pack_weights(const float* w, void* packed, const rg_pack_param
   const long total = (long)rows16 * pack_rowlen(p, red);
   (void)total;
   if (((uintptr_t)packed) & 15) RG_FAIL(RG_ERR_BAD_SHAPE, "pack_weights: packed buffer must be 16B aligned");
+  if (p->src_channels_last) {
+    const long rowlen = pack_rowlen(p, red);
+    const int ntap = p->ntap[0] * p->ntap[1] * p->ntap[2];
+    if (rowlen != (long)ntap * red32 && hipMemsetAsync(packed, 0, (size_t)total * 2, (hipStream_t)s) != hipSuccess)  // FLAT row tails
+      RG_FAIL(RG_ERR_HIP, "pack_weights: memset failed");
+    if (!p->swap) {
+      const long n = (long)rows16 * ntap * (red32 / 8);
+      hipLaunchKernelGGL(pack_cl_rows_kernel, dim3(grid_for(n, 256, 1 << 16)), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32, rowlen);
+    } else {
+      const long nblk = (long)((red32 + 63) / 64) * ((rows16 + 63) / 64) * ntap;
+      if (nblk >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "pack_weights: grid too large");
+      hipLaunchKernelGGL(pack_cl_transpose_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32, rowlen);
+    }
+    RG_CHECK_LAUNCH();
+    return RG_OK;
+  }
   const int nblk = ((rows16 + PK_R - 1) / PK_R) * ((red32 + 63) / 64);
   hipLaunchKernelGGL(pack_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, *p, rows, red, rows16, red32, pack_rowlen(p, red));
   RG_CHECK_LAUNCH();

@@ -996,6 +996,19 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t s) {
 
 extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int accumulate,
                                void* workspace, size_t ws_bytes, rg_stream s) {
+  return rg_conv3d_wgrad2(g, x, dw, p, accumulate ? 1 : 0, workspace, ws_bytes, s);
+}
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s][i]: the final pass when dw lives in the kernels' own [a][tap][b] order
+__global__ void wgrad_sum_kernel(const float* part, float* out, long total, int nsplit, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = accumulate ? out[i] : 0.f;
+  for (int s = 0; s < nsplit; ++s) v += part[s * total + i];
+  out[i] = v;
+}
+extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int flags,
+                                void* workspace, size_t ws_bytes, rg_stream s) {
+  const int accumulate = flags & 1, dw_cl = (flags >> 1) & 1;
   CL5 G, X;
   int rc;
   if ((rc = wgrad_check(g, x, p, &G, &X))) return rc;
@@ -1008,7 +1021,8 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
   if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   if (!dw) RG_FAIL(RG_ERR_BAD_SHAPE, "wgrad: null dw");
   WgradArgs a;
-  a.g = G.p; a.x = X.p; a.part = (float*)workspace;
+  const bool direct = dw_cl && ns == 1 && !accumulate;  // the single split's "partial" sums are dw itself
+  a.g = G.p; a.x = X.p; a.part = direct ? dw : (float*)workspace;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
   a.RD = p->R[0]; a.RH = p->R[1]; a.RW = p->R[2];
   a.TD = p->T[0]; a.TH = p->T[1]; a.TW = p->T[2];
@@ -1075,6 +1089,7 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
     default: WG_ROW(9, 1); break;  // 144x144 tile as 1x3 waves of 144x48: 12 fragment reads per 27 MFMAs
   }
   RG_CHECK_LAUNCH();
+  if (direct) return RG_OK;
   const float* fin = (const float*)workspace;
   int nfin = ns;
   if (nfold) {
@@ -1083,7 +1098,8 @@ extern "C" int rg_conv3d_wgrad(const rg_tensor* g, const rg_tensor* x, float* dw
     RG_CHECK_LAUNCH();
     fin = folded; nfin = nfold;
   }
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(G.C * ((X.C + 63) / 64)), dim3(256), 0, st, fin, dw, G.C, X.C, ntaps, nfin, accumulate);
+  if (dw_cl) hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((total_el + 255) / 256)), dim3(256), 0, st, fin, dw, (long)total_el, nfin, accumulate);
+  else hipLaunchKernelGGL(wgrad_finish_kernel, dim3(G.C * ((X.C + 63) / 64)), dim3(256), 0, st, fin, dw, G.C, X.C, ntaps, nfin, accumulate);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

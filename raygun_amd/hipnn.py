@@ -8,6 +8,7 @@ would have returned (``scope()`` tracks the nesting).
 """
 import contextlib
 import functools
+import os
 import threading
 
 import torch
@@ -16,6 +17,7 @@ import torch.nn as nn
 from . import ops
 
 _tls = threading.local()
+CL_WEIGHTS = os.environ.get("RAYGUN_AMD_CL_WEIGHTS", "1") != "0"
 
 
 @contextlib.contextmanager
@@ -96,7 +98,17 @@ _ACT_OF.update({nn.ReLU: lambda m: ("relu", 0.0), nn.LeakyReLU: lambda m: ("leak
 
 
 class Conv3d(nn.Conv3d):
-    """torch.nn.Conv3d on the implicit-GEMM kernel.  padding int/tuple/'valid'/'same'; padding_mode zeros|reflect."""
+    """torch.nn.Conv3d on the implicit-GEMM kernel.  padding int/tuple/'valid'/'same'; padding_mode zeros|reflect.
+
+    The fp32 master weight keeps torch's logical shape (Cout,Cin,KD,KH,KW) and state_dict key but lives in
+    torch.channels_last_3d memory, [Cout][KD][KH][KW][Cin]: that is the order the weight-gradient kernels accumulate in and
+    the packed MFMA operand is stored in, so the gradient needs no transpose pass, Adam (elementwise on the storage) updates
+    in place and the forward packing is a straight convert.  RAYGUN_AMD_CL_WEIGHTS=0 keeps contiguous masters."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if CL_WEIGHTS and self.weight.shape[2] * self.weight.shape[3] * self.weight.shape[4] > 1:
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last_3d)
 
     def _pads(self):
         if isinstance(self.padding, str):

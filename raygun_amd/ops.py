@@ -65,6 +65,17 @@ def cl_empty_dw(n, c, d, h, w, device):
     return cl_empty(n, c, w, h, d, device).transpose(2, 4)
 
 
+def is_dense(t):
+    """Non-overlapping and dense: the storage is a permutation of the elements (contiguous, channels_last_3d, ...)."""
+    return t.is_contiguous() or (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)) or \
+        (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def is_cl_weight(w):
+    """5-D fp32 weight in torch.channels_last_3d memory ([dim0][KD][KH][KW][dim1]) — hipnn.Conv3d keeps its masters that way."""
+    return w.dim() == 5 and w.dtype == torch.float32 and not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last_3d)
+
+
 def is_cl(t):
     if t.dtype != torch.bfloat16 or t.dim() != 5 or not t.is_cuda:
         return False
@@ -182,9 +193,11 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     if key in cache:
         return cache[key]
     wd = w.detach()
-    if wd.dtype != torch.float32 or not wd.is_contiguous():
+    src_cl = is_cl_weight(wd)
+    if not src_cl and (wd.dtype != torch.float32 or not wd.is_contiguous()):
         wd = wd.float().contiguous()
     p = rg_pack_params()
+    p.src_channels_last = int(src_cl)
     p.dim0, p.dim1 = wd.shape[0], wd.shape[1]
     K = wd.shape[2:]
     nt = ntap if ntap is not None else K
@@ -265,8 +278,11 @@ def _igemm(x, wp, bias, y, p):
            lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} R{tuple(p.R)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)}")
 
 
-def _wgrad(g, x, p, shape):
-    dw = torch.empty(shape, dtype=torch.float32, device=g.device)
+def _wgrad(g, x, p, shape, channels_last=False):
+    """fp32 weight gradient of logical `shape` (a, b, KD, KH, KW); channels_last: in torch.channels_last_3d memory, which is
+    the [a][tap][b] order the kernels accumulate in (no transpose pass; with one row split no reduction pass either)."""
+    dw = torch.empty(shape, dtype=torch.float32, device=g.device,
+                     memory_format=torch.channels_last_3d if channels_last else torch.contiguous_format)
     ns = C.c_int32(0)
     dg, dx = desc(g), desc(x)
     nbytes = _lib.lib().rg_conv3d_wgrad_workspace_bytes(C.byref(dg), C.byref(dx), C.byref(p), C.byref(ns))
@@ -274,8 +290,9 @@ def _wgrad(g, x, p, shape):
         _lib.check(-1, "rg_conv3d_wgrad_workspace_bytes")
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
     _timed(_conv_flops(p, g.shape[0], x.shape[1], g.shape[1]),
-           lambda: _lib.check(_lib.lib().rg_conv3d_wgrad(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p), 0,
-                                                         C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_conv3d_wgrad"),
+           lambda: _lib.check(_lib.lib().rg_conv3d_wgrad2(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p),
+                                                          2 if channels_last else 0, C.c_void_p(ws.data_ptr()), nbytes, _stream()),
+                              "rg_conv3d_wgrad"),
            lambda: f"g{tuple(g.shape)} x{tuple(x.shape)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)} ns{ns.value}")
     return dw
 
@@ -384,7 +401,7 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
                              ooffset=(0, 0, 0), cout=weight.shape[0])
-            dw = _wgrad(g, x, p, weight.shape).to(weight.dtype)
+            dw = _wgrad(g, x, p, weight.shape, channels_last=is_cl_weight(weight)).to(weight.dtype)
         if db is not None:
             db = db.to(weight.dtype)
         return gx, dw, db, None, None, None, None, None

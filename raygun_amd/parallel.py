@@ -38,6 +38,18 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _flat(g):
+    """The gradient's storage as a 1-D tensor (an element-wise sum does not care about the order): contiguous tensors as they
+    are, channels-last conv-weight gradients through their channels-last permutation (zero-copy)."""
+    if g.is_contiguous():
+        return g
+    if g.dim() == 5 and g.is_contiguous(memory_format=torch.channels_last_3d):
+        return g.permute(0, 2, 3, 4, 1).reshape(-1)
+    if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last):
+        return g.permute(0, 2, 3, 1).reshape(-1)
+    raise RuntimeError("raygun_amd.GradSync: gradients must be dense (contiguous or channels-last)")
+
+
 class GradSync:
     """Callable(list_of_params): average .grad over all ranks (no-op for world size 1).
 
@@ -69,9 +81,7 @@ class GradSync:
         g = p.grad
         if g is None:
             return
-        if not g.is_contiguous():
-            raise RuntimeError("raygun_amd.GradSync: gradients must be contiguous")
-        self._pending[id(p)] = (g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending[id(p)] = (g, dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def __call__(self, params):
         ws = world_size()
@@ -84,9 +94,7 @@ class GradSync:
         rest.sort(key=lambda g: -g.numel())
         handles = [h for _, h in started]
         for g in rest:
-            if not g.is_contiguous():
-                raise RuntimeError("raygun_amd.GradSync: gradients must be contiguous")
-            handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            handles.append(dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in handles:
             h.wait()
         inv = 1.0 / ws

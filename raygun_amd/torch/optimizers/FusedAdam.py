@@ -33,10 +33,15 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous()
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("raygun_amd.FusedAdam: fp32 contiguous master parameters expected")
+                # the kernel walks the STORAGE: any dense layout works (contiguous or channels-last conv weights) as long as
+                # parameter, gradient and both moments share it
+                if p.dtype != torch.float32 or not ops.is_dense(p):
+                    raise RuntimeError("raygun_amd.FusedAdam: fp32 dense master parameters expected")
+                if g.dtype != torch.float32 or g.stride() != p.stride():
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if st[k].stride() != p.stride():  # e.g. a state dict loaded from a contiguous checkpoint
+                        st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
                 ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
                                group["weight_decay"], int(st["step"]))
                 # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
