@@ -117,3 +117,29 @@ def test_norm_mode_and_init_helpers_work_on_dropin_modules():
     assert all(float(m.bias.abs().sum()) == 0 for m in g.modules() if getattr(m, "bias", None) is not None)
     set_norm_mode(g, "fix_norms")
     assert g.training and all(not m.training for m in g.modules() if "norm" in type(m).__name__.lower())
+
+
+def test_channels_last_master_weights_interchange_with_reference_checkpoints():
+    """hipnn.Conv3d keeps its fp32 master weight in torch.channels_last_3d memory.  That is a memory detail:
+    logical shape, state_dict keys and values interchange with plain torch modules (= reference checkpoints) both ways, and
+    load_state_dict / .to() / init in place keep the layout."""
+    import torch
+    from raygun_amd import hipnn
+    torch.manual_seed(3)
+    ref = torch.nn.Conv3d(5, 7, 3)
+    mine = hipnn.Conv3d(5, 7, 3)
+    assert tuple(mine.weight.shape) == (7, 5, 3, 3, 3)
+    if hipnn.CL_WEIGHTS:
+        assert mine.weight.is_contiguous(memory_format=torch.channels_last_3d) and not mine.weight.is_contiguous()
+    mine.load_state_dict(ref.state_dict())                       # reference checkpoint -> ours
+    assert torch.equal(mine.weight.detach(), ref.weight.detach()) and torch.equal(mine.bias.detach(), ref.bias.detach())
+    if hipnn.CL_WEIGHTS:
+        assert mine.weight.is_contiguous(memory_format=torch.channels_last_3d)   # layout survives load_state_dict
+        torch.nn.init.kaiming_normal_(mine.weight)
+        assert mine.weight.is_contiguous(memory_format=torch.channels_last_3d)   # ... and in-place init (init_weights)
+    back = torch.nn.Conv3d(5, 7, 3)
+    back.load_state_dict(mine.state_dict())                      # ours -> a plain torch module
+    assert torch.equal(back.weight.detach(), mine.weight.detach())
+    assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+    one = hipnn.Conv3d(4, 2, 1)                                  # 1x1x1 kernels stay contiguous
+    assert one.weight.is_contiguous()
