@@ -162,6 +162,10 @@ int rg_loss_fwd_bwd(int kind, const rg_tensor* pred, const rg_tensor* target, co
 /* ---- fused Adam over one flat fp32 parameter (torch.optim.Adam semantics, optimizers/utils.py:4-9) */
 int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, float grad_scale, rg_stream s);
+/* same, and refreshes the packed bf16 forward operand (rg_pack_weights of the same channels-last master, swap = 0, all taps) in the
+ * same pass; `packed` must have been produced by rg_pack_weights with `pp` before (its pad entries are kept). */
+int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, float grad_scale, void* packed, const rg_pack_params* pp, rg_stream s);
 
 /* ---- mutex watershed (affogato.segmentation.compute_mws_segmentation, called at segment.py:197-199) */
 typedef struct {

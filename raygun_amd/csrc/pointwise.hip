@@ -662,8 +662,12 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
   pi = pi - (lr / bc1) * (mi / denom);
 }
 // 16 bytes per lane and stream (7 streams of 4 B/element: the step is pure HBM traffic); `vec` = all four pointers 16-B aligned
+// `pk`: also refresh the bf16 forward operand of a channels-last conv weight while the updated values are in registers
+// (storage order [row][tap][k]; packed [row][tap][k padded to red32] resp. FLAT rows of rowlen): pack_cl_rows_kernel's pass
+// over the master weights disappears.  Pad lanes / rows of the packed buffer keep the zeros of its first full packing.
+struct AdamPack { bf16_t* out; int red, red32, ntap; long rowlen; };
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2_sqrt, float gscale, int vec) {
+                            float wd, float bc1, float bc2_sqrt, float gscale, int vec, AdamPack pk) {
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
   const long n4 = vec ? n / 4 : 0;
   for (long i = tid; i < n4; i += nthr) {
@@ -674,6 +678,12 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
     adam_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
     adam_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    if (pk.out) {  // red % 4 == 0 (host-checked): the four values share (row, tap)
+      const long e = i * 4, rt = e / pk.red; const int k = (int)(e - rt * pk.red);
+      const long row = rt / pk.ntap; const int tap = (int)(rt - row * pk.ntap);
+      bf16x4 o = (bf16x4){(short)f2bf(pp.x), (short)f2bf(pp.y), (short)f2bf(pp.z), (short)f2bf(pp.w)};
+      *(bf16x4*)(pk.out + row * pk.rowlen + (long)tap * pk.red32 + k) = o;
+    }
   }
   for (long i = n4 * 4 + tid; i < n; i += nthr) {
     float pi = p[i], mi = m[i], vi = v[i];
@@ -683,12 +693,27 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 }
 extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int32_t step, float grad_scale, rg_stream s) {
+  return rg_adam_step_pack(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, nullptr, s);
+}
+extern "C" int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int32_t step, float grad_scale, void* packed, const rg_pack_params* pp, rg_stream s) {
   if (n == 0) return RG_OK;
+  AdamPack pk; memset(&pk, 0, sizeof(pk));
+  if (packed) {
+    int rows, red;
+    if (!pp || pack_dims(pp, &rows, &red) || !pp->src_channels_last || pp->swap || (red & 3) || (((uintptr_t)packed) & 7))
+      RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: needs a channels-last source, swap = 0 and a reduced channel count that is a multiple of 4");
+    for (int d = 0; d < 3; ++d) if (pp->ntap[d] != pp->K[d] || pp->k0[d] != 0 || pp->kstep[d] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: full tap set only");
+    if ((int64_t)rows * pp->K[0] * pp->K[1] * pp->K[2] * red != n) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: packing parameters do not match n");
+    pk.out = (bf16_t*)packed; pk.red = red; pk.red32 = round_up(red, pack_align(pp)); pk.ntap = pp->K[0] * pp->K[1] * pp->K[2];
+    pk.rowlen = pack_rowlen(pp, red);
+  }
   if (!p || !g || !m || !v || n < 0 || step < 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const int vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  if (pk.out && (!vec || (n & 3))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: 16-byte aligned tensors with a multiple of 4 elements expected");
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2), grad_scale, vec);
+                     weight_decay, bc1, sqrtf(bc2), grad_scale, vec, pk);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

@@ -213,6 +213,8 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     _lib.check(_lib.lib().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
                "rg_pack_weights")
     cache[key] = out
+    if src_cl and not swap and ntap is None and tuple(k0) == (0, 0, 0) and tuple(kstep) == (1, 1, 1) and red % 4 == 0:
+        cache["fwd_pack"] = (out, p)  # FusedAdam refreshes this operand in its own pass (adam_step_)
     return out
 
 
@@ -837,7 +839,20 @@ def weighted_mse(pred, target, weight):
 
 # ---------------------------------------------------------------------------------------------- Adam
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    """In-place fused Adam on flat fp32 tensors (torch.optim.Adam semantics; optimizers/utils.py:4-9)."""
+    """In-place fused Adam on dense fp32 tensors of one layout (torch.optim.Adam semantics; optimizers/utils.py:4-9).
+    If `p` is a channels-last conv weight whose forward operand is packed and current, the kernel rewrites that bf16
+    operand too (same values, same rounding as rg_pack_weights) and the cache entry follows the new version."""
+    cache = getattr(p, "_rg_pack_cache", None)
+    fwd = None
+    if cache is not None and cache.get("ver") == (p._version, p.data_ptr()):
+        fwd = cache.get("fwd_pack")
+    if fwd is not None and os.environ.get("RAYGUN_AMD_ADAM_PACK", "1") != "0":
+        _lib.check(_lib.lib().rg_adam_step_pack(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                                grad_scale, C.c_void_p(fwd[0].data_ptr()), C.byref(fwd[1]), _stream()),
+                   "rg_adam_step_pack")
+        return fwd
     _lib.check(_lib.lib().rg_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                        C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                        grad_scale, _stream()), "rg_adam_step")
+    return None

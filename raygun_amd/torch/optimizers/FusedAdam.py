@@ -42,8 +42,10 @@ class FusedAdam(torch.optim.Optimizer):
                 for k in ("exp_avg", "exp_avg_sq"):
                     if st[k].stride() != p.stride():  # e.g. a state dict loaded from a contiguous checkpoint
                         st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
-                ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
-                               group["weight_decay"], int(st["step"]))
+                fwd = ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
+                                     group["weight_decay"], int(st["step"]))
                 # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
                 torch.autograd.graph.increment_version(p)
+                if fwd is not None:  # the forward operand was refreshed in the same pass: it is current for the new version
+                    p._rg_pack_cache = {"ver": (p._version, p.data_ptr()), (0, (0, 0, 0), (1, 1, 1), None): fwd[0], "fwd_pack": fwd}
         return loss

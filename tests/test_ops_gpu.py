@@ -258,3 +258,28 @@ def test_shape_errors_raise():
         ops.conv3d(torch.zeros(1, 2, 4, 4, 4, device=dev), torch.zeros(1, 3, 3, 3, 3, device=dev))
     with pytest.raises(RuntimeError):
         ops.conv3d(torch.zeros(1, 1, 2, 2, 2, device=dev), torch.zeros(1, 1, 3, 3, 3, device=dev))
+
+
+@pytest.mark.parametrize("cin,cout", [(72, 40), (432, 144), (12, 12)])
+def test_fused_adam_refreshes_packed_forward_operand(cin, cout):
+    """FusedAdam rewrites the bf16 forward operand of a channels-last conv weight in its own pass (rg_adam_step_pack): the
+    refreshed buffer must equal a fresh rg_pack_weights of the updated master bit for bit, and the updated master must equal
+    the plain fused step's."""
+    from raygun_amd import hipnn, ops
+    from raygun_amd.torch.optimizers import FusedAdam
+    if not hipnn.CL_WEIGHTS:
+        pytest.skip("channels-last master weights are disabled")
+    dev = torch.device("cuda")
+    conv = hipnn.Conv3d(cin, cout, 3).to(dev)
+    x = rnd((1, cin, 5, 6, 7), 11).to(dev)
+    opt = FusedAdam(conv.parameters(), lr=1e-2)
+    for it in range(2):
+        opt.zero_grad()
+        conv(x).float().pow(2).mean().backward()      # forward packs the operand (iteration 0) / reuses the refreshed one
+        before = conv.weight.detach().clone()
+        opt.step()
+        cache = conv.weight._rg_pack_cache
+        assert cache["ver"] == (conv.weight._version, conv.weight.data_ptr()) and "fwd_pack" in cache
+        fresh = ops.pack_weights(conv.weight.detach().clone(memory_format=torch.preserve_format), swap=0)
+        assert torch.equal(cache[(0, (0, 0, 0), (1, 1, 1), None)].view(torch.int16), fresh.view(torch.int16))
+        assert not torch.equal(before, conv.weight.detach())
