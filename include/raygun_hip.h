@@ -43,6 +43,10 @@ typedef struct {
 } rg_tensor;
 
 int rg_version(void);
+/* measurement aid: with rg_profile_enable(1) the conv / weight-gradient entry points record a HIP event pair around their dominant
+ * kernel on the launch stream; rg_profile_drain returns the elapsed milliseconds in call order (synchronises) and resets. */
+void rg_profile_enable(int on);
+int rg_profile_drain(float* ms, int cap);
 const char* rg_last_error_string(void);
 /* name (template instantiation) of the main kernel launched by this thread's last conv/wgrad call — profiling aid */
 const char* rg_last_kernel_name(void);

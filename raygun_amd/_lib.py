@@ -68,6 +68,8 @@ _SIGS = {
     "rg_loss_fwd_bwd": (C.c_int, [C.c_int, _T, _T, _T, C.c_float, C.c_float, _T, C.c_void_p, C.c_void_p]),
     "rg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "rg_profile_enable": (None, [C.c_int]),
+    "rg_profile_drain": (C.c_int, [C.c_void_p, C.c_int]),
     "rg_adam_step_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
     "rg_mws_workspace_bytes": (C.c_int64, [_P(rg_mws_params)]),

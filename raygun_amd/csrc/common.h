@@ -16,6 +16,7 @@ typedef unsigned short bf16_t;
 // ---- error plumbing -------------------------------------------------------
 void rg_set_error(const char* fmt, ...);
 void rg_set_kernel_name(const char* fmt, ...);  // name of the dominant kernel of the last call (profiling aid)
+void rg_prof_mark(hipStream_t st);              // HIP event before / after the dominant kernel when rg_profile_enable(1)
 #define RG_FAIL(code, ...) do { rg_set_error(__VA_ARGS__); return (code); } while (0)
 #define RG_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
   rg_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return RG_ERR_HIP; } } while (0)

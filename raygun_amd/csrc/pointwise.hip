@@ -17,6 +17,37 @@ void rg_set_kernel_name(const char* fmt, ...) {
 extern "C" const char* rg_last_kernel_name(void) { return g_kname; }
 extern "C" int rg_version(void) { return 100; }
 
+// ---- kernel timing aid (bench.py's roofline): HIP events around the DOMINANT kernel of a call, on the launch stream -------
+// A weight-gradient call launches its main kernel plus small reduction passes; timing the whole call from outside would not
+// agree with rocprofv3's per-kernel average.  Off by default (no events, no overhead); not thread-safe (one profiling host
+// thread).
+#include <vector>
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_ev;   // begin/end pairs in call order
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+  hipEvent_t e = nullptr;
+  if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); }
+  else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+  return e;
+}
+void rg_prof_mark(hipStream_t st) {  // called by a launcher right before and right after its dominant kernel
+  if (!g_prof_on) return;
+  hipEvent_t e = prof_event();
+  if (e && hipEventRecord(e, st) == hipSuccess) g_prof_ev.push_back(e);
+}
+extern "C" void rg_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" int rg_profile_drain(float* ms, int cap) {  // elapsed ms of every marked kernel since the last drain, in call order
+  int n = 0;
+  for (size_t i = 0; i + 1 < g_prof_ev.size(); i += 2) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof_ev[i + 1]) == hipSuccess && hipEventElapsedTime(&t, g_prof_ev[i], g_prof_ev[i + 1]) == hipSuccess && n < cap) ms[n++] = t;
+  }
+  for (hipEvent_t e : g_prof_ev) g_prof_pool.push_back(e);
+  g_prof_ev.clear();
+  return n;
+}
+
 static inline int grid_for(long n, int block = 256, int cap = 1 << 20) {
   long g = (n + block - 1) / block; if (g > cap) g = cap; if (g < 1) g = 1; return (int)g;
 }

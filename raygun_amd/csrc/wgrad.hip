@@ -1032,6 +1032,7 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
   a.A = G.C; a.B = X.C; a.alanes = G.lanes; a.blanes = X.lanes;
   a.M = (long)G.N * a.RD * a.RH * a.RW; a.rows_per_split = rps; a.nsplit = ns;
   hipStream_t st = (hipStream_t)s;
+  rg_prof_mark(st);
   KwGeom kg;
   if (const int kind = wgrad_kw_kind(G, X, p, fa, fb, &kg)) {
     WgradKwArgs ka; ka.w = a;
@@ -1088,6 +1089,7 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     case 8: WG_ROW(8, 2); break;
     default: WG_ROW(9, 1); break;  // 144x144 tile as 1x3 waves of 144x48: 12 fragment reads per 27 MFMAs
   }
+  rg_prof_mark(st);
   RG_CHECK_LAUNCH();
   if (direct) return RG_OK;
   const float* fin = (const float*)workspace;

@@ -234,6 +234,9 @@ def profile_start():
     """Start recording a HIP-event pair (on torch's current stream = the launch stream) around every conv kernel."""
     global _prof
     _prof = []
+    L = _lib.lib()
+    L.rg_profile_enable(1)  # weight-gradient calls: event pair around the main kernel only, inside the library
+    L.rg_profile_drain(None, 0)
 
 
 def profile_stop():
@@ -241,11 +244,18 @@ def profile_stop():
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
+    L = _lib.lib()
+    L.rg_profile_enable(0)
+    marked = [r for r in rec or [] if r[4]]
+    buf = (C.c_float * max(1, len(marked)))()
+    got = L.rg_profile_drain(buf, len(marked))
+    inner = dict(zip(map(id, marked), buf[:got])) if got == len(marked) else {}
     out = {}
-    for name, flops, e0, e1 in rec or []:
+    for r in rec or []:
+        name, flops, e0, e1, _ = r
         d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
         d["launches"] += 1
-        d["ms"] += e0.elapsed_time(e1)
+        d["ms"] += inner.get(id(r), None) or e0.elapsed_time(e1)
         d["flops"] += flops
     return out
 
@@ -253,7 +263,7 @@ def profile_stop():
 profile_shapes = False  # True: key the records by kernel name AND problem shape (diagnostics)
 
 
-def _timed(flops, fn, tag=None):
+def _timed(flops, fn, tag=None, marked=False):
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,7 +273,7 @@ def _timed(flops, fn, tag=None):
     name = _lib.lib().rg_last_kernel_name().decode()
     if profile_shapes and tag is not None:
         name += " " + tag()
-    _prof.append((name, flops, e0, e1))
+    _prof.append((name, flops, e0, e1, marked))
     return r
 
 
@@ -295,7 +305,7 @@ def _wgrad(g, x, p, shape, channels_last=False):
            lambda: _lib.check(_lib.lib().rg_conv3d_wgrad2(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p),
                                                           2 if channels_last else 0, C.c_void_p(ws.data_ptr()), nbytes, _stream()),
                               "rg_conv3d_wgrad"),
-           lambda: f"g{tuple(g.shape)} x{tuple(x.shape)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)} ns{ns.value}")
+           lambda: f"g{tuple(g.shape)} x{tuple(x.shape)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)} ns{ns.value}", marked=True)
     return dw
 
 
