@@ -73,7 +73,10 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
                                     C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
                                     C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment")
-    return labels.cpu().numpy().astype(np.uint64)
+    out = labels.cpu().numpy().astype(np.uint64)
+    if out.flat[0] == np.uint64(0xFFFFFFFFFFFFFFFF):
+        raise RuntimeError("raygun_amd.compute_mws_segmentation: the device pass made no progress (internal error)")
+    return out
 
 
 def prepare_weights(affs, sep, mask_thresh, max_affinity_value):
