@@ -29,21 +29,63 @@ __device__ __forceinline__ unsigned order_desc(float w) {
   return ~b;                                        // descending weight first
 }
 
-__global__ void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys, unsigned* count,
-                                 int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx) {
-  const long N = (long)Z * Y * X, total = N * n_off;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i / N); const long u = i % N;
-    const int x = (int)(u % X), y = (int)((u / X) % Y), z = (int)(u / ((long)X * Y));
-    const int z2 = z + offsets[3 * k], y2 = y + offsets[3 * k + 1], x2 = x + offsets[3 * k + 2];
-    bool ok = (unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X;
-    if (k >= n_attr) ok = ok && (z % sz == 0) && (y % sy == 0) && (x % sx == 0);
-    if (ok && mask) ok = mask[u] && mask[((long)z2 * Y + y2) * X + x2];
-    if (ok) {
-      const unsigned pos = atomicAdd(count, 1u);
-      keys[pos] = ((u64)order_desc(affs[i]) << 32) | (u64)(unsigned)i;
+// One thread per voxel: the (z, y, x) decode and the stride-grid test happen once, only the channels that can hold an edge
+// are read (3 attractive ones for 999 voxels in 1000 at stride 10), and a wavefront reserves its keys with ONE atomic.
+__global__ __launch_bounds__(256) void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys,
+                                                       unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx) {
+  const unsigned N = (unsigned)((long)Z * Y * X);
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  u64 valid = 0;
+  if (u < N && (!mask || mask[u])) {
+    const int x = (int)(u % (unsigned)X), y = (int)((u / (unsigned)X) % (unsigned)Y), z = (int)(u / ((unsigned)X * (unsigned)Y));
+    const int kmax = (z % sz == 0 && y % sy == 0 && x % sx == 0) ? n_off : n_attr;
+    for (int k = 0; k < kmax; ++k) {
+      const int z2 = z + offsets[3 * k], y2 = y + offsets[3 * k + 1], x2 = x + offsets[3 * k + 2];
+      if ((unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X &&
+          (!mask || mask[((long)z2 * Y + y2) * X + x2]))
+        valid |= 1ull << k;
     }
   }
+  const int nv = __popcll(valid);
+  int incl = nv;
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;  // wave-uniform
+  unsigned base = 0;
+  if (lane == 63) base = atomicAdd(count, (unsigned)total);
+  base = __shfl(base, 63) + (unsigned)(incl - nv);
+  while (valid) {
+    const int k = __builtin_ctzll(valid); valid &= valid - 1;
+    const unsigned id = (unsigned)k * N + u;
+    keys[base++] = ((u64)order_desc(affs[id]) << 32) | (u64)id;
+  }
+}
+
+// segment.py:188-194 on the device, bit for bit as numpy computes it in float32: mask = mean over the channels (sequential
+// sum, then one division) > thresh ; weights = 1 - affs, the attractive channels flipped back as (w * -1) + 1.
+__global__ __launch_bounds__(256) void mws_prepare_kernel(const float* affs, float* weights, unsigned char* mask, long N, int n_off,
+                                                         int n_attr, float thresh) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  float sum = 0.f;
+  for (int k = 0; k < n_off; ++k) {
+    const float a = affs[(long)k * N + u];
+    sum = k ? __fadd_rn(sum, a) : a;
+    float w = __fsub_rn(1.f, a);
+    if (k < n_attr) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f);
+    weights[(long)k * N + u] = w;
+  }
+  mask[u] = __fdiv_rn(sum, (float)n_off) > thresh ? 1 : 0;
+}
+extern "C" int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,
+                              float thresh, rg_stream s) {
+  if (!affs || !weights || !mask || n_voxels <= 0 || n_offsets <= 0 || n_attractive < 0 || n_attractive > n_offsets)
+    RG_FAIL(RG_ERR_BAD_SHAPE, "mws_prepare: bad arguments");
+  if ((n_voxels + 255) / 256 > 0x7fffffffL) RG_FAIL(RG_ERR_UNSUPPORTED, "mws_prepare: volume too large");
+  hipLaunchKernelGGL(mws_prepare_kernel, dim3((unsigned)((n_voxels + 255) / 256)), dim3(256), 0, (hipStream_t)s, affs, weights, mask,
+                     (long)n_voxels, n_offsets, n_attractive, thresh);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
 }
 
 struct MwsState {
@@ -64,26 +106,83 @@ __device__ bool mws_has_mutex(const MwsState& s, int ra, int rb) {
 
 // ---- round-based Kruskal: the whole chip walks a WINDOW over the sorted edge list -----------------------------------------
 // A window entry is a pending edge: its slot in the sorted list (= its rank in the order), the last known roots of its two
-// ends, and the mutex-list lengths seen at its last mutex check.  Every round (two grid barriers):
+// ends, and the mutex-list lengths seen at its last mutex check.  Every round:
 //   A  find both roots.  Same root -> retired (clusters only grow).  Attractive edge between two clusters that already hold a
 //      mutex -> retired (mutexes are never removed).  Otherwise claim both roots: claim[r] = earliest pending edge at r.
-//   B  an edge that is the earliest pending edge at BOTH its roots executes exactly as in the sequential order (nothing earlier
-//      can touch either cluster any more).  An attractive edge that is the earliest at a root whose cluster holds NO mutex
-//      executes too, whatever waits at the other end: until its turn that cluster stays untouched and mutex-free, so the
-//      sequential algorithm would merge it then, and merging it early changes nothing an earlier edge can observe (it
-//      contributes no mutex and no earlier edge ends in it) — the Boruvka step.  Everything else stays pending.
-// The earliest pending edge always executes, so every round makes progress; the partition is the sequential one.
-struct MwsCtl { unsigned bar, surv[2], pool_used, stalled, rounds, pad[2]; };
+//   B  decide, with parents and lists as phase A saw them (lists are only changed in C):
+//      * an edge that is the earliest pending edge at BOTH roots executes as in the sequential order: nothing earlier can
+//        touch either cluster any more;
+//      * a repulsive edge that is the earliest at ONE of its roots, b, executes: b cannot merge with anything before its turn,
+//        so the mutex it adds separates two clusters that are distinct at its turn, and the only edges that could notice it
+//        early (attractive edges between the two clusters) end in b, hence come later in the order;
+//      * an attractive edge (a, b) that is the earliest at b executes (b joins a) when every cluster p that holds a mutex
+//        with b is QUIET — no pending edge at p is earlier than this edge — or already holds a mutex with a.  Then p cannot
+//        become part of a's cluster before the edge's turn, so the sequential algorithm finds no mutex and merges; and no
+//        earlier edge can observe b's mutexes inside a's cluster, because it would have to end in such a p.  A cluster
+//        without mutexes is the trivial case (the Boruvka step).
+//      Everything else stays pending.  The earliest pending edge always executes, so every round makes progress.
+//   C  (only in rounds that need it) mutex-list surgery, by atomic appends to the CURRENT roots: a merged cluster's list is
+//      appended to its root's list, a repulsive edge appends one node to either side.
+// The partition is the sequential one; root ids and list order differ, labels are canonical.
+struct MwsCtl { unsigned bar, surv[2], nops[2], pool_used, stalled, rounds; };
 #define MWS_RETIRED 0xffffffffu
 #define MWS_ATTR 0x80000000u
 #define MWS_THREADS 1024
+#define MWS_QUIET_MAX 48          // longest mutex list examined for the quiet-partner rule
+#define MWS_PAIR_BITS 20          // cache of root pairs known to hold a mutex (sound: roots never come back, mutexes stay)
+
+__device__ __forceinline__ u64 mws_pair_key(int x, int y) { return (x < y ? ((u64)(unsigned)x << 32) | (unsigned)y : ((u64)(unsigned)y << 32) | (unsigned)x) + 1ull; }
+__device__ __forceinline__ unsigned mws_pair_hash(u64 k) { k *= 0x9E3779B97F4A7C15ull; return (unsigned)(k >> (64 - MWS_PAIR_BITS)); }
+__device__ bool mws_pair_known(const u64* pairs, int x, int y) {
+  const u64 k = mws_pair_key(x, y);
+  unsigned h = mws_pair_hash(k);
+  for (int i = 0; i < 4; ++i, h = (h + 1) & ((1u << MWS_PAIR_BITS) - 1)) {
+    const u64 v = pairs[h];
+    if (v == k) return true;
+    if (v == 0) return false;
+  }
+  return false;
+}
+__device__ void mws_pair_insert(u64* pairs, int x, int y) {
+  const u64 k = mws_pair_key(x, y);
+  unsigned h = mws_pair_hash(k);
+  for (int i = 0; i < 4; ++i, h = (h + 1) & ((1u << MWS_PAIR_BITS) - 1)) {
+    const u64 v = atomicCAS(&pairs[h], 0ull, k);
+    if (v == 0 || v == k) return;
+  }
+}
+// exact when parents and lists are stable (phase A); in phase B a concurrent merge can only turn a "yes" into a "no"
+__device__ bool mws_mutex_between(const MwsState& s, u64* pairs, int ra, int rb) {
+  if (mws_pair_known(pairs, ra, rb)) return true;
+  if (mws_has_mutex(s, ra, rb)) { mws_pair_insert(pairs, ra, rb); return true; }
+  return false;
+}
+// may the attractive edge `slot` merge cluster c into `other` ahead of its turn?  (c's claim is this edge.)
+// 1 = yes, 0 = not now, -1 = never: the two clusters hold a mutex (c's whole list is walked, so this is the exact test)
+__device__ int mws_quiet(const MwsState& s, u64* pairs, const u64* claim, int c, int other, unsigned slot, unsigned round) {
+  const int n = s.cnt[c];
+  if (n == 0) return 1;
+  if (n > MWS_QUIET_MAX) return 0;
+  int ok = 1;
+  for (int node = s.head[c]; node >= 0; node = s.pool[node].y) {
+    const int rp = mws_find(s.parent, s.pool[node].x);
+    if (rp == other) { mws_pair_insert(pairs, c, other); return -1; }
+    const u64 cl = claim[rp];
+    if (ok && (unsigned)(cl >> 32) == round && 0xffffffffu - (unsigned)cl < slot)  // an earlier edge is pending at this partner
+      if (s.cnt[other] == 0 || !mws_mutex_between(s, pairs, other, rp)) ok = 0;
+  }
+  return ok;
+}
+__device__ __forceinline__ void mws_list_append(const MwsState& s, int r, int h, int t, int c) {
+  const int old = atomicExch(&s.tail[r], t);
+  if (old >= 0) s.pool[old].y = h; else s.head[r] = h;
+  atomicAdd(&s.cnt[r], c);
+}
 
 // Grid barrier of the persistent kernel.  One thread per workgroup does the device-scope release / acquire (the workgroup
 // barriers around it order the other waves' accesses with it); measured on MI355X: 2.2 us at 32 workgroups, 3.7 us at 64,
 // 8.5 us at 128 — and 62 us at 128 when every wave fences, so the grid stays small: rounds are latency-bound.
-__device__ int g_mws_fence_all;
 __device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target, unsigned nwg) {
-  if (g_mws_fence_all) __threadfence();
   __syncthreads();
   target += nwg;
   if (threadIdx.x == 0) {
@@ -93,12 +192,11 @@ __device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target
     __threadfence();
   }
   __syncthreads();
-  if (g_mws_fence_all) __threadfence();
 }
 
 __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys, const unsigned* count, const int* offsets, MwsState s,
-                                                                u64* claim, uint4* win0, uint4* win1, MwsCtl* ctl, int Z, int Y, int X,
-                                                                int n_off, int n_attr, unsigned cap, unsigned pool_cap) {
+                                                                u64* claim, u64* pairs, uint4* win0, uint4* win1, int2* ops, MwsCtl* ctl,
+                                                                int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap) {
   __shared__ int lin[64];
   if (threadIdx.x < n_off && threadIdx.x < 64)
     lin[threadIdx.x] = (offsets[3 * threadIdx.x] * Y + offsets[3 * threadIdx.x + 1]) * X + offsets[3 * threadIdx.x + 2];
@@ -129,14 +227,9 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       }
       const int a = mws_find(s.parent, (int)e.y), b = mws_find(s.parent, (int)e.z);
       bool retired = a == b;
-      if (!retired && (e.w & MWS_ATTR)) {
-        const int ca = s.cnt[a], cb = s.cnt[b];
-        if (ca && cb) {
-          const unsigned sig = MWS_ATTR | (unsigned)(ca + cb);
-          if ((int)e.y != a || (int)e.z != b || e.w != sig) retired = mws_has_mutex(s, a, b);
-          e.w = sig;
-        }
-      }
+      // known mutex between the two clusters: the edge can never merge them (the exact test runs in phase B, once, when the
+      // edge is about to execute; the pair cache lets every other edge between the same two clusters leave right here)
+      if (!retired && (e.w & MWS_ATTR) && s.cnt[a] && s.cnt[b]) retired = mws_pair_known(pairs, a, b);
       if (!retired) {
         const u64 mine = tag | (u64)(0xffffffffu - e.x);
         atomicMax(&claim[a], mine); atomicMax(&claim[b], mine);
@@ -148,32 +241,32 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
     mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
     // ---- phase B
     unsigned* surv = &ctl->surv[round & 1];
+    unsigned* nops = &ctl->nops[round & 1];
     for (unsigned i0 = tid - lane; i0 < n; i0 += T) {  // whole waves iterate together (ballots below)
       const unsigned i = i0 + lane;
       uint4 e = make_uint4(MWS_RETIRED, 0, 0, 0);
       if (i < n) e = win[i];
       bool keep = false;
+      int2 op = make_int2(-1, -1);  // (child, -1): append child's list to its root ; (a, b) with b >= 0: new mutex a | b
       if (e.x != MWS_RETIRED) {
         const int a = (int)e.y, b = (int)e.z;
         const u64 mine = tag | (u64)(0xffffffffu - e.x);
         const bool fa = claim[a] == mine, fb = claim[b] == mine;
         if (e.w & MWS_ATTR) {
-          if (fa && fb) {
-            s.parent[b] = a;
-            if (s.head[b] >= 0) {  // splice b's mutex list onto a's
-              if (s.head[a] >= 0) s.pool[s.tail[a]].y = s.head[b]; else s.head[a] = s.head[b];
-              s.tail[a] = s.tail[b]; s.cnt[a] += s.cnt[b];
-            }
-          } else if (fb && s.cnt[b] == 0) s.parent[b] = a;
-          else if (fa && s.cnt[a] == 0) s.parent[a] = b;
-          else keep = true;
-        } else if (fa && fb) {
-          const unsigned na = atomicAdd(&ctl->pool_used, 2u), nb = na + 1;
-          if (nb < pool_cap) {
-            s.pool[na] = make_int2(b, s.head[a]); if (s.head[a] < 0) s.tail[a] = (int)na; s.head[a] = (int)na; s.cnt[a] += 1;
-            s.pool[nb] = make_int2(a, s.head[b]); if (s.head[b] < 0) s.tail[b] = (int)nb; s.head[b] = (int)nb; s.cnt[b] += 1;
+          int child = -1, q = 0;
+          if (fa && fb) {  // nothing else can touch either cluster this round: the list walk is exact
+            if (s.cnt[a] && s.cnt[b] && mws_mutex_between(s, pairs, a, b)) q = -1;
+            else child = s.cnt[b] <= s.cnt[a] ? b : a;
+          } else {
+            if (fb) { q = mws_quiet(s, pairs, claim, b, a, e.x, round); if (q > 0) child = b; }
+            if (fa && q == 0) { q = mws_quiet(s, pairs, claim, a, b, e.x, round); if (q > 0) child = a; }
           }
-        } else keep = true;
+          if (child >= 0) {
+            s.parent[child] = child == b ? a : b;
+            if (s.cnt[child] > 0) op = make_int2(child, -1);
+          } else keep = q == 0;
+        } else if (fa || fb) op = make_int2(a, b);
+        else keep = true;
       }
       const u64 km = __ballot(keep);
       if (km) {
@@ -182,11 +275,36 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
         base = __shfl(base, 0);
         if (keep) wout[base + __popcll(km & ((1ull << lane) - 1ull))] = e;
       }
+      const u64 om = __ballot(op.x >= 0);
+      if (om) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(nops, (unsigned)__popcll(om));
+        base = __shfl(base, 0);
+        if (op.x >= 0) ops[base + __popcll(om & ((1ull << lane) - 1ull))] = op;
+      }
     }
     mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
     const unsigned ns2 = __hip_atomic_load(surv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned no = __hip_atomic_load(nops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     next += want;
-    if (tid == 0) { ctl->surv[(round + 1) & 1] = 0; ctl->rounds = round; }  // the other counter: everyone read it before the last barrier
+    if (tid == 0) { ctl->surv[(round + 1) & 1] = 0; ctl->nops[(round + 1) & 1] = 0; ctl->rounds = round; }  // everyone read those before the last barrier
+    // ---- phase C
+    if (no) {
+      for (unsigned i = tid; i < no; i += T) {
+        const int2 op = ops[i];
+        if (op.y < 0) mws_list_append(s, mws_find(s.parent, op.x), s.head[op.x], s.tail[op.x], s.cnt[op.x]);
+        else {
+          const unsigned na = atomicAdd(&ctl->pool_used, 2u), nb = na + 1;
+          if (nb < pool_cap) {
+            // only .x is written: .y is -1 from the initial fill, and once the node is published by the exchange below another
+            // thread may already be linking its own chain behind it
+            s.pool[na].x = op.y; mws_list_append(s, mws_find(s.parent, op.x), (int)na, (int)na, 1);
+            s.pool[nb].x = op.x; mws_list_append(s, mws_find(s.parent, op.y), (int)nb, (int)nb, 1);
+          }
+        }
+      }
+      mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
+    }
     if (ns2 == n || round > (1u << 23)) {  // no edge retired although the earliest one always can: never expected; leave instead of spinning
       if (tid == 0) ctl->stalled = 1;
       break;
@@ -206,7 +324,7 @@ __global__ void mws_first_kernel(MwsState s, const unsigned char* mask, int* fir
     if (mask && !mask[i]) continue;
     const int r = mws_find(s.parent, (int)i);
     s.root[i] = r;
-    atomicMin(&first[r], (int)i);
+    if (first[r] > (int)i) atomicMin(&first[r], (int)i);  // a stale read only costs a redundant atomic
   }
 }
 __global__ void mws_flag_kernel(MwsState s, const unsigned char* mask, const int* first, unsigned* flags, long N) {
@@ -222,7 +340,7 @@ __global__ void mws_label_kernel(MwsState s, const unsigned char* mask, const in
 
 #define MWS_WIN_CAP (1u << 20)
 #define MWS_MAX_WGS 32
-struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_win, off_keys2, off_cnt, off_state, off_pool, off_first, off_flags, off_rank, off_tmp, tmp_bytes, total; };
+struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_pairs, off_ops, off_win, off_keys2, off_cnt, off_state, off_pool, off_first, off_flags, off_rank, off_tmp, tmp_bytes, total; };
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
   if (!p || p->shape[0] <= 0 || p->shape[1] <= 0 || p->shape[2] <= 0 || p->n_offsets <= 0 || p->n_attractive < 0 ||
@@ -245,7 +363,9 @@ static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
   o += al((size_t)q->N * 4) * 5; q->off_pool = o;
   q->pool_nodes = 2 * grid * (p->n_offsets - p->n_attractive) + 2;
   o += al((size_t)q->pool_nodes * 8); q->off_claim = o;
-  o += al((size_t)q->N * 8); q->off_win = o;
+  o += al((size_t)q->N * 8); q->off_pairs = o;
+  o += al((size_t)8 << MWS_PAIR_BITS); q->off_ops = o;
+  o += al((size_t)MWS_WIN_CAP * 8); q->off_win = o;
   o += 2 * al((size_t)MWS_WIN_CAP * 16); q->off_first = o;
   o += al((size_t)q->N * 4); q->off_flags = o;
   o += al((size_t)q->N * 4); q->off_rank = o;
@@ -285,8 +405,8 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     RG_FAIL(RG_ERR_HIP, "mws: memset failed");
   hipLaunchKernelGGL(mws_init_kernel, dim3(blocks), dim3(256), 0, st, S, first, flags, q.N);
   RG_CHECK_LAUNCH();
-  int eblocks = (int)((q.N * p->n_offsets + 255) / 256); if (eblocks > 16384) eblocks = 16384;
-  hipLaunchKernelGGL(mws_edges_kernel, dim3(eblocks), dim3(256), 0, st, affs, offsets, mask, keys, count, Z, Y, X, p->n_offsets,
+  if (p->n_offsets > 64) RG_FAIL(RG_ERR_UNSUPPORTED, "mws: at most 64 offsets");
+  hipLaunchKernelGGL(mws_edges_kernel, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, st, affs, offsets, mask, keys, count, Z, Y, X, p->n_offsets,
                      p->n_attractive, p->strides[0], p->strides[1], p->strides[2]);
   RG_CHECK_LAUNCH();
   size_t tb = q.tmp_bytes;
@@ -302,16 +422,14 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
       wgs = cus * per_cu < MWS_MAX_WGS ? cus * per_cu : MWS_MAX_WGS;
       if (const char* e = getenv("RG_MWS_WGS")) { const int v = atoi(e); if (v >= 1 && v <= cus * per_cu) wgs = v; }
     }
-    { int fa = getenv("RG_MWS_FENCE_ALL") ? 1 : 0; hipMemcpyToSymbolAsync(HIP_SYMBOL(g_mws_fence_all), &fa, 4, 0, hipMemcpyHostToDevice, st); hipStreamSynchronize(st); }
     const u64* kp = keys2; const unsigned* cp = count; const int* op = offsets;
-    u64* claim = (u64*)(w + q.off_claim);
+    u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
     uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
     MwsCtl* ctl = (MwsCtl*)(w + q.off_cnt + 64);
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes;
-    if (p->n_offsets > 64) RG_FAIL(RG_ERR_UNSUPPORTED, "mws: at most 64 offsets");
-    if (hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
-    void* args[] = {&kp, &cp, &op, &S, &claim, &win0, &win1, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap};
+    if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
+    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap};
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
       RG_FAIL(RG_ERR_HIP, "mws: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (getenv("RG_MWS_STATS")) {

@@ -36,9 +36,10 @@ def build_neighborhood(neighborhood=None, n_diagonals=8):
 
 
 def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, strides=None, mask=None,
-                             randomize_strides=False, device=None):
+                             randomize_strides=False, device=None, as_tensor=False):
     """GPU mutex watershed.  weights: (n_offsets, Z, Y, X) float32 edge weights (numpy or torch), offsets: (n_offsets, 3),
-    mask: (Z, Y, X) bool or None.  Returns a uint64 ndarray (Z, Y, X) like affogato (0 = masked out)."""
+    mask: (Z, Y, X) bool or None.  Returns a uint64 ndarray (Z, Y, X) like affogato (0 = masked out); with as_tensor=True
+    the labels stay on the device (int64 tensor, same bits) and nothing is copied back."""
     if randomize_strides:
         raise NotImplementedError("raygun_amd: randomize_strides is not built (the reference passes strides only)")
     dev = torch.device(device if device is not None else "cuda")
@@ -61,7 +62,7 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
     p.n_offsets, p.n_attractive, p.randomize_strides = w.shape[0], int(number_of_attractive_channels), 0
     labels = torch.zeros(tuple(w.shape[1:]), dtype=torch.int64, device=dev)
     if labels.numel() == 0:
-        return labels.cpu().numpy().astype(np.uint64)
+        return labels if as_tensor else labels.cpu().numpy().astype(np.uint64)
     L = _lib.lib()
     nbytes = L.rg_mws_workspace_bytes(C.byref(p))
     if nbytes < 0:
@@ -73,19 +74,33 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
                                     C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
                                     C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment")
+    if as_tensor:
+        return labels  # all-ones labels (= -1) would mean the device pass made no progress; callers that keep the tensor check
     out = labels.cpu().numpy().astype(np.uint64)
     if out.flat[0] == np.uint64(0xFFFFFFFFFFFFFFFF):
         raise RuntimeError("raygun_amd.compute_mws_segmentation: the device pass made no progress (internal error)")
     return out
 
 
-def prepare_weights(affs, sep, mask_thresh, max_affinity_value):
-    """segment.py:188-194 (mask from the channel mean; weights = 1 - affs with the attractive channels flipped back)."""
-    mask = np.mean(affs, axis=0) > mask_thresh * max_affinity_value
-    affs = 1 - affs
-    affs[:sep] = affs[:sep] * -1
-    affs[:sep] = affs[:sep] + 1
-    return affs, mask
+def prepare_weights(affs, sep, mask_thresh, max_affinity_value, device=None):
+    """segment.py:188-194 on the device (rg_mws_prepare): mask = channel mean > mask_thresh * max_affinity_value,
+    weights = 1 - affs with the attractive channels flipped back — rounded exactly as numpy's float32 arithmetic.
+    affs: (n_offsets, Z, Y, X) float32 ndarray or tensor.  Returns device tensors (weights float32, mask uint8)."""
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("raygun_amd.prepare_weights runs on the MI355X only (no CPU fallback)")
+    a = torch.as_tensor(np.ascontiguousarray(affs, dtype=np.float32) if isinstance(affs, np.ndarray) else affs)
+    a = a.to(dev, torch.float32).contiguous()
+    if a.dim() != 4:
+        raise ValueError(f"affs must be (n_offsets, Z, Y, X); got {tuple(a.shape)}")
+    w = torch.empty_like(a)
+    m = torch.empty(tuple(a.shape[1:]), dtype=torch.uint8, device=dev)
+    if m.numel():
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().rg_mws_prepare(C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                 m.numel(), a.shape[0], int(sep), float(np.float32(mask_thresh * max_affinity_value)),
+                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_prepare")
+    return w, m
 
 
 def segment_blocks(weights, offsets, sep, strides, mask, block_shape, rank=0, world=1):
@@ -125,7 +140,8 @@ def mutex_segment(config_path, affs=None):
                                "config['file'] needs the `zarr` package, which is not installed") from e
         f = zarr.open(seg_config["file"], "a")
         affs = f[seg_config["aff_ds"]][:]
-    affs = np.array(affs, dtype=np.float32)
+    if not torch.is_tensor(affs):
+        affs = np.asarray(affs, dtype=np.float32)
     weights, mask = prepare_weights(affs, seg_config["sep"], seg_config["mask_thresh"], seg_config["max_affinity_value"])
     seg = compute_mws_segmentation(weights, neighborhood, seg_config["sep"], strides=[10, 10, 10], mask=mask)
     if ("save" in seg_config and not seg_config["save"]) or f is None:

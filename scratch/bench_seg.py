@@ -21,6 +21,7 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
         w, m = O.prepare(affs.copy())
         wt = torch.from_numpy(w).cuda(); mt = torch.from_numpy(m.astype(np.uint8)).cuda()
         S.compute_mws_segmentation(wt[:, :16, :16, :16].contiguous(), nb, 3, (10, 10, 10), mt[:16, :16, :16].contiguous())
+        S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         seg = S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mt)
         torch.cuda.synchronize(); tg = time.perf_counter() - t0

@@ -46,7 +46,10 @@ def test_oracle_edge_cases():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,strides,use_mask,structured", [
     ((6, 6, 6), (1, 1, 1), True, False), ((9, 10, 11), (2, 2, 2), True, False), ((16, 16, 16), (1, 1, 1), False, False),
-    ((24, 20, 28), (3, 2, 4), True, True), ((32, 32, 32), (10, 10, 10), True, True), ((1, 40, 40), (1, 4, 4), False, True)])
+    ((24, 20, 28), (3, 2, 4), True, True), ((32, 32, 32), (10, 10, 10), True, True), ((1, 40, 40), (1, 4, 4), False, True),
+    # more edges than one window of the round-based pass holds; dense mutexes (stride 1) exercise the early-merge rules
+    ((48, 48, 48), (1, 1, 1), False, False), ((40, 48, 56), (2, 2, 2), True, True), ((64, 64, 64), (4, 4, 4), True, False),
+    ((56, 56, 56), (1, 1, 1), True, True), ((72, 72, 72), (10, 10, 10), False, True)])
 def test_gpu_labels_bit_exact(shape, strides, use_mask, structured):
     from raygun_amd.segment import compute_mws_segmentation
     w = synth.uniform((8,) + shape, 11, 0, 1)
@@ -72,6 +75,22 @@ def test_gpu_mutex_segment_reference_pipeline():
     ref = O.compute_mws_segmentation(ww, O.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m)
     assert (build_neighborhood() == O.neighborhood(8)).all()
     assert (seg == ref).all() and seg.max() > 1 and (seg[~m] == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_prepare_bit_exact():
+    """rg_mws_prepare == the numpy float32 arithmetic of segment.py:188-194 (oracle.mws.prepare), bit for bit, including
+    voxels whose channel mean sits right at the threshold."""
+    from raygun_amd.segment import prepare_weights
+    shape = (9, 14, 21)
+    affs = synth.uniform((20,) + shape, 31, 0, 1).astype(np.float32)
+    affs[:, 0] = 0.5          # mean exactly at the threshold: not > 0.5
+    affs[:, 1, 0] = np.float32(0.5) + np.float32(2.0 ** -24)
+    for sep, thresh, mx in ((3, 0.5, 1.0), (5, 0.25, 2.0)):
+        ww, m = O.prepare(affs.copy(), sep, thresh, mx)
+        w, mk = prepare_weights(affs.copy(), sep, thresh, mx)
+        assert (w.cpu().numpy().view(np.uint32) == ww.view(np.uint32)).all()
+        assert (mk.cpu().numpy().astype(bool) == m).all()
 
 
 @pytest.mark.gpu
