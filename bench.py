@@ -6,6 +6,10 @@ valid, 259 146 829 parameters, num_affs 3) affinity train step on a synthetic 19
 forward + WeightedMSELoss_MTLSD + backward + Adam (+ RCCL gradient all-reduce for N > 1), bf16 storage /
 fp32 accumulate.  value = input Mvoxels/s over the whole job (196^3 * N / step time), "scaling": "weak".
 `--workload cyclegan` times the 3-D CycleGAN link train step at 128^3 (BASELINE's second figure, ms/step).
+`--workload predict` times block-wise volume prediction (first half: 196^3 -> 104^3 blocks of the
+U-Net with 20 affinity channels over a synthetic uint8 volume resident in HBM); `--workload segment` times the mutex
+watershed (second half: segment.py's prepare + 20-offset / sep 3 / stride 10 mutex watershed of a synthetic structured
+affinity volume resident in HBM).
 
 One JSON line is printed by rank 0, carrying `roofline` (dominant conv kernel, HIP events on the launch stream,
 algorithmic FLOPs = 2*rows*taps*Cin*Cout) and `cpu_baseline` (the oracle's plain-PyTorch CPU restatement on a
@@ -32,8 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan"])
-    ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 for unet, 128 for cyclegan)")
+    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment"])
+    ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0)
     return ap.parse_args()
@@ -163,6 +167,141 @@ def cpu_baseline(workload, size):
                 sample=f"1 link train step of the CPU restatement at {size}^3 (work ratio to 128^3: {(128 / size) ** 3:.0f}x), {dt:.1f} s")
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MWS_BYTES_PER_VOXEL = 88  # 20 float32 affinity channels read once + one uint64 label written
+
+
+def structured_affs(size, seed, device):
+    """Synthetic 20-channel affinities with object structure: high inside smooth blobs, low across their boundaries, plus
+    20 % uniform noise (the random-initialised U-Net of the predict workload would give pure noise)."""
+    g = torch.Generator(device=device).manual_seed(1000 + seed)
+    r = torch.arange(size, device=device, dtype=torch.float32)
+    f = torch.sin(r / 9.1 + 1)[:, None, None] * torch.sin(r / 11.3)[None, :, None] * torch.sin(r / 8.7 + 1.0)[None, None, :]
+    base = (f.abs() > 0.2).float() * 0.8 + 0.1
+    return 0.8 * base[None] + 0.2 * torch.rand((20, size, size, size), generator=g, device=device)
+
+
+def main_aux(a, rank, local, world, dev):
+    """--workload predict / segment.  No collective on either path (8e): ranks work on their own volume."""
+    from raygun_amd import _lib, ops, predict as P, segment as S, synth
+    import ctypes as C
+    import numpy as np
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if a.workload == "predict":
+        from raygun_amd.torch.models import MTLSDModel
+        size = a.size or 404
+        torch.manual_seed(1234)
+        with torch.device(dev):
+            model = MTLSDModel(num_affs=20).eval()
+        g = torch.Generator(device=dev).manual_seed(77 + rank)
+        vol = torch.randint(0, 256, (size,) * 3, generator=g, device=dev, dtype=torch.uint8)
+        nblk = len(P.enumerate_blocks(vol.shape, *P.roi_geometry(3, [196] * 3, [104] * 3)))
+        units = nblk * 104 ** 3
+
+        def step():
+            return P.predict_volume(model, vol, input_shape=[196] * 3, output_shape=[104] * 3, out_dtypes=[np.uint8, np.uint8])
+    else:
+        size = a.size or 256
+        affs = structured_affs(size, rank, dev)
+        nb = S.build_neighborhood()
+        units = size ** 3
+
+        def step():
+            w, m = S.prepare_weights(affs, 3, 0.5, 1.0)
+            return S.compute_mws_segmentation(w, nb, 3, strides=[10, 10, 10], mask=m, as_tensor=True)
+
+    for _ in range(a.warmup):
+        out = step()
+    barrier()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if a.workload == "segment":  # the library bracketed the persistent Kruskal kernel of every call
+        buf = (C.c_float * (a.steps + 1))()
+        n = _lib.lib().rg_profile_drain(buf, a.steps + 1)
+        prof = {"mws_rounds_kernel": dict(launches=n, ms=float(sum(buf[:n])), flops=0.0)}
+        ops.profile_stop()
+        if int(out.view(-1)[0].item()) == -1:
+            raise RuntimeError("mutex watershed made no progress")
+    else:
+        prof = ops.profile_stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank != 0:
+            torch.distributed.destroy_process_group()
+            return
+    ms = dt / a.steps * 1e3
+    if a.workload == "segment":
+        d = prof["mws_rounds_kernel"]
+        avg = d["ms"] / max(1, d["launches"])
+        ach = units * MWS_BYTES_PER_VOXEL / (avg * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="mws_rounds_kernel", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, launches_per_step=1, avg_launch_ms=round(avg, 4),
+                        note="algorithmic bytes = 88 B/voxel (20 fp32 channels + u64 label); the pass is a dependency-ordered "
+                             "union-find over sorted edges, bound by round latency and device-scope atomics, not by HBM streaming")
+        res = dict(metric="Mvoxels/sec mutex watershed (prepare + 20 offsets, sep 3, strides 10)", unit="Mvoxels/s", dtype="f32 keys / i32 union-find",
+                   config=dict(workload=f"segment {size}^3 per GPU: synthetic structured 20-channel affinities (blobs + 20% noise), "
+                                        "segment.py:188-199 pipeline, labels left in HBM", parallelism=f"replicas x{world}"),
+                   segments=int(out.max().item()))
+    else:
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches_per_step=dom[1]["launches"] // a.steps,
+                        avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
+        res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks", unit="Mvoxels/s", dtype="bf16",
+                   config=dict(workload=f"predict {size}^3 uint8 volume per GPU in {nblk} blocks, MTLSDModel(UNet ngf12 x6 3-level valid, "
+                                        "20 affinities + 10 LSDs), uint8 destinations in HBM", parallelism=f"blocks sharded x{world}"),
+                   blocks_per_s=round(nblk * world / (dt / a.steps), 2))
+    res.update(value=round(units * world / (dt / a.steps) / 1e6, 3), n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
+               higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic", roofline=roofline)
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline_aux(a.workload, a.cpu_size)
+        except Exception as e:
+            res["cpu_baseline"] = dict(error=repr(e))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline_aux(workload, size):
+    import numpy as np
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    if workload == "segment":
+        from oracle import mws as OM
+        size = size or 192
+        affs = structured_affs(size, 0, "cpu").numpy()
+        t0 = time.time()
+        w, m = OM.prepare(affs)
+        OM.compute_mws_segmentation(w, OM.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m)
+        dt = time.time() - t0
+        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=1, kind="port",
+                    sample=f"numpy prepare + oracle/mws.c (sequential Kruskal, as affogato is single-threaded) on the same synthetic affinities at {size}^3, {dt:.1f} s")
+    from oracle import torch_ref as O
+    from raygun_amd import synth
+    m = O.MTLSDModel(num_affs=20).eval()
+    x = torch.from_numpy(synth.uniform((1, 1, 196, 196, 196), 42, 0, 1))
+    with torch.no_grad():
+        t0 = time.time()
+        for _ in range(2):
+            m(x)
+        dt = (time.time() - t0) / 2
+    return dict(value=104 ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
+                sample=f"forward of the CPU restatement on 2 blocks of 196^3 (torch {torch.__version__} fp32, oneDNN), {dt:.1f} s per block")
+
+
 def main():
     a = parse()
     from raygun_amd import ops, parallel
@@ -173,6 +312,8 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if a.workload in ("predict", "segment"):
+        return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
     step, info = (build_unet if a.workload == "unet" else build_cyclegan)(dev, size, seed=rank)
     sync = parallel.GradSync()

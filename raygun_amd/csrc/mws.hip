@@ -430,8 +430,11 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes;
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
     void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap};
+    rg_set_kernel_name("mws_rounds_kernel");
+    rg_prof_mark(st);
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
       RG_FAIL(RG_ERR_HIP, "mws: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
+    rg_prof_mark(st);
     if (getenv("RG_MWS_STATS")) {
       MwsCtl h; unsigned ne = 0;
       hipStreamSynchronize(st);

@@ -45,11 +45,17 @@ def enumerate_blocks(volume_shape, read, write, context):
     return [(z + context[0], y + context[1], x + context[2]) for z in axes[0] for y in axes[1] for x in axes[2]]
 
 
-def _to_destination(out, dtype):
+_TORCH_DT = {np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8, np.dtype(np.int16): torch.int16,
+             np.dtype(np.int32): torch.int32, np.dtype(np.float16): torch.float16}
+
+
+def _to_destination(out, dtype, on_device=False):
     """worker.py:133-149: integer destinations get *iinfo.max + clamp, float ones pass through."""
     if np.issubdtype(np.dtype(dtype), np.integer):
         info = np.iinfo(dtype)
         out = torch.clamp(out * float(info.max), float(info.min), float(info.max))
+    if on_device:
+        return out.to(_TORCH_DT[np.dtype(dtype)])
     return out.cpu().numpy().astype(dtype)
 
 
@@ -61,23 +67,31 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
 
     model: callable taking a (1,1,z,y,x) tensor and returning a tensor or tuple of tensors (worker.py:116-119).
     Returns (list of destination ndarrays, number of blocks this rank processed).  Destinations are zero where no block
-    wrote (borders; other ranks' blocks when world > 1)."""
-    source = np.asarray(source)
+    wrote (borders; other ranks' blocks when world > 1).  A `source` that is a tensor already on the GPU keeps the whole
+    pipeline there: the destinations are device tensors and nothing crosses PCIe."""
+    resident = torch.is_tensor(source) and source.is_cuda
+    if resident:
+        src_np_dtype = np.dtype(str(source.dtype).replace("torch.", ""))
+        if device is None:
+            device = source.device
+    else:
+        source = np.asarray(source)
+        src_np_dtype = source.dtype
     if source.ndim != 3:
         raise ValueError("source must be a (Z, Y, X) volume")
-    if not np.issubdtype(source.dtype, np.integer):
+    if not np.issubdtype(src_np_dtype, np.integer):
         raise TypeError("source must be an integer volume (worker.py:109-110 normalises with np.iinfo)")
     dev = torch.device(device if device is not None else "cuda")
     read, write, context = roi_geometry(ndims, input_shape, output_shape, read_size, crop)
     blocks = enumerate_blocks(source.shape, read, write, context)
     mine = parallel.shard_blocks(len(blocks), rank, world)
-    info = np.iinfo(source.dtype)
+    info = np.iinfo(src_np_dtype)
     scale, shift = 1.0 / float(info.max), -float(info.min) / float(info.max)
     if scaleShift_input is not None:  # worker.py:112-114
         scale, shift = scale * scaleShift_input[0], shift * scaleShift_input[0] + scaleShift_input[1]
     if hasattr(model, "eval"):
         model.eval()
-    src_t = torch.from_numpy(np.ascontiguousarray(source))
+    src_t = source if resident else torch.from_numpy(np.ascontiguousarray(source))
     n_done = 0
     for bi in mine:
         wz, wy, wx = blocks[bi]
@@ -94,7 +108,9 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
             for i, o in enumerate(outs):
                 c = o.shape[1]
                 dt = np.float32 if out_dtypes is None else out_dtypes[i]
-                destinations.append(np.zeros(((c,) if c > 1 else ()) + tuple(source.shape), dtype=dt))
+                shp = ((c,) if c > 1 else ()) + tuple(source.shape)
+                destinations.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
+        out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in destinations}
         for o, dest in zip(outs, destinations):
             o = o.detach().float()[0]
             if crop and crop != 0 and input_shape is None:
@@ -102,7 +118,7 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
             if tuple(o.shape[-3:]) != tuple(write):
                 off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
                 o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
-            arr = _to_destination(o if dest.ndim == 4 else o[0], dest.dtype)
+            arr = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], resident)
             dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = arr
         n_done += 1
     return destinations, n_done

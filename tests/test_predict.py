@@ -57,3 +57,9 @@ def test_blockwise_equals_whole_volume():
     a, na = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1], rank=0, world=2)
     b, nb_ = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1], rank=1, world=2)
     assert na + nb_ == 8 and np.array_equal(a[0] + b[0], dests[0])
+    # source already in HBM: same numbers, destinations stay on the device
+    r, nr = P.predict_volume(net, torch.from_numpy(vol).to(dev), input_shape=[36] * 3, output_shape=[20] * 3, scaleShift_input=[2, -1])
+    assert nr == 8 and r[0].is_cuda and np.array_equal(r[0].cpu().numpy(), dests[0])
+    r8, _ = P.predict_volume(lambda t: torch.sigmoid(net(t)), torch.from_numpy(vol).to(dev), input_shape=[36] * 3, output_shape=[20] * 3,
+                             out_dtypes=[np.uint8])
+    assert r8[0].dtype == torch.uint8 and np.array_equal(r8[0].cpu().numpy(), d8[0])
