@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment"])
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
+    ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=0)
     return ap.parse_args()
@@ -208,6 +209,8 @@ def main_aux(a, rank, local, world, dev):
     else:
         size = a.size or 256
         affs = structured_affs(size, rank, dev)
+        if a.affs == "noise":
+            affs = torch.rand(affs.shape, generator=torch.Generator(device=dev).manual_seed(5 + rank), device=dev)
         nb = S.build_neighborhood()
         units = size ** 3
 
@@ -250,7 +253,8 @@ def main_aux(a, rank, local, world, dev):
                         note="algorithmic bytes = 88 B/voxel (20 fp32 channels + u64 label); the pass is a dependency-ordered "
                              "union-find over sorted edges, bound by round latency and device-scope atomics, not by HBM streaming")
         res = dict(metric="Mvoxels/sec mutex watershed (prepare + 20 offsets, sep 3, strides 10)", unit="Mvoxels/s", dtype="f32 keys / i32 union-find",
-                   config=dict(workload=f"segment {size}^3 per GPU: synthetic structured 20-channel affinities (blobs + 20% noise), "
+                   config=dict(workload=f"segment {size}^3 per GPU: synthetic " + ("structured 20-channel affinities (blobs + 20% noise), "
+                                        if a.affs == "blobs" else "pure-noise 20-channel affinities (adversarial: one giant cluster), ") +
                                         "segment.py:188-199 pipeline, labels left in HBM", parallelism=f"replicas x{world}"),
                    segments=int(out.max().item()))
     else:

@@ -30,11 +30,14 @@ __device__ __forceinline__ unsigned order_desc(float w) {
 }
 
 // One thread per voxel: the (z, y, x) decode and the stride-grid test happen once, only the channels that can hold an edge
-// are read (3 attractive ones for 999 voxels in 1000 at stride 10), and a wavefront reserves its keys with ONE atomic.
-__global__ __launch_bounds__(256) void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys,
-                                                       unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx) {
+// are read (3 attractive ones for 999 voxels in 1000 at stride 10), and a 1024-voxel workgroup reserves its keys with ONE
+// atomic (one per wavefront was the bottleneck: 262 144 serialised atomics on one counter at 256^3).
+#define MWS_EDGE_THREADS 1024
+__global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys,
+                                                                    unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx) {
+  __shared__ unsigned wave_base[MWS_EDGE_THREADS / 64];
   const unsigned N = (unsigned)((long)Z * Y * X);
-  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const unsigned u = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 valid = 0;
   if (u < N && (!mask || mask[u])) {
     const int x = (int)(u % (unsigned)X), y = (int)((u / (unsigned)X) % (unsigned)Y), z = (int)(u / ((unsigned)X * (unsigned)Y));
@@ -49,15 +52,20 @@ __global__ __launch_bounds__(256) void mws_edges_kernel(const float* affs, const
   const int nv = __popcll(valid);
   int incl = nv;
   for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
-  const int total = __shfl(incl, 63);
-  if (total == 0) return;  // wave-uniform
-  unsigned base = 0;
-  if (lane == 63) base = atomicAdd(count, (unsigned)total);
-  base = __shfl(base, 63) + (unsigned)(incl - nv);
+  if (lane == 63) wave_base[wave] = (unsigned)incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (int w = 0; w < MWS_EDGE_THREADS / 64; ++w) { const unsigned t = wave_base[w]; wave_base[w] = total; total += t; }
+    const unsigned base = total ? atomicAdd(count, total) : 0u;
+    for (int w = 0; w < MWS_EDGE_THREADS / 64; ++w) wave_base[w] += base;
+  }
+  __syncthreads();
+  unsigned pos = wave_base[wave] + (unsigned)(incl - nv);
   while (valid) {
     const int k = __builtin_ctzll(valid); valid &= valid - 1;
     const unsigned id = (unsigned)k * N + u;
-    keys[base++] = ((u64)order_desc(affs[id]) << 32) | (u64)id;
+    keys[pos++] = ((u64)order_desc(affs[id]) << 32) | (u64)id;
   }
 }
 
@@ -100,7 +108,13 @@ __device__ __forceinline__ int mws_find(int* parent, int x) {
 }
 __device__ bool mws_has_mutex(const MwsState& s, int ra, int rb) {
   if (s.cnt[ra] > s.cnt[rb]) { const int t = ra; ra = rb; rb = t; }
-  for (int n = s.head[ra]; n >= 0; n = s.pool[n].y) if (mws_find(s.parent, s.pool[n].x) == rb) return true;
+  for (int n = s.head[ra]; n >= 0;) {
+    const int2 nd = s.pool[n];
+    const int rp = mws_find(s.parent, nd.x);
+    if (rp == rb) return true;
+    if (rp != nd.x) s.pool[n].x = rp;  // any voxel of the partner cluster stands for it: keep the walk one hop long next time
+    n = nd.y;
+  }
   return false;
 }
 
@@ -124,11 +138,17 @@ __device__ bool mws_has_mutex(const MwsState& s, int ra, int rb) {
 //   C  (only in rounds that need it) mutex-list surgery, by atomic appends to the CURRENT roots: a merged cluster's list is
 //      appended to its root's list, a repulsive edge appends one node to either side.
 // The partition is the sequential one; root ids and list order differ, labels are canonical.
-struct MwsCtl { unsigned bar, surv[2], nops[2], pool_used, stalled, rounds; };
+struct MwsCtl { unsigned bar, surv[2], nops[2], pool_used, stalled, rounds; unsigned long long t[4], visits; };  // t: 100 MHz ticks in A, B, C (tid 0)
 #define MWS_RETIRED 0xffffffffu
 #define MWS_ATTR 0x80000000u
 #define MWS_THREADS 1024
-#define MWS_QUIET_MAX 48          // longest mutex list examined for the quiet-partner rule
+#ifndef MWS_NESTED_MAX
+#define MWS_NESTED_MAX 16  // longest list walked to show that a busy partner already holds a mutex with the other side
+#endif
+#ifndef MWS_QUIET_MAX
+#define MWS_QUIET_MAX 48
+#endif
+//         // longest mutex list examined for the quiet-partner rule
 #define MWS_PAIR_BITS 20          // cache of root pairs known to hold a mutex (sound: roots never come back, mutexes stay)
 
 __device__ __forceinline__ u64 mws_pair_key(int x, int y) { return (x < y ? ((u64)(unsigned)x << 32) | (unsigned)y : ((u64)(unsigned)y << 32) | (unsigned)x) + 1ull; }
@@ -164,12 +184,16 @@ __device__ int mws_quiet(const MwsState& s, u64* pairs, const u64* claim, int c,
   if (n == 0) return 1;
   if (n > MWS_QUIET_MAX) return 0;
   int ok = 1;
-  for (int node = s.head[c]; node >= 0; node = s.pool[node].y) {
-    const int rp = mws_find(s.parent, s.pool[node].x);
+  for (int node = s.head[c]; node >= 0;) {
+    const int2 nd = s.pool[node];
+    const int rp = mws_find(s.parent, nd.x);
+    if (rp != nd.x) s.pool[node].x = rp;
+    node = nd.y;
     if (rp == other) { mws_pair_insert(pairs, c, other); return -1; }
     const u64 cl = claim[rp];
     if (ok && (unsigned)(cl >> 32) == round && 0xffffffffu - (unsigned)cl < slot)  // an earlier edge is pending at this partner
-      if (s.cnt[other] == 0 || !mws_mutex_between(s, pairs, other, rp)) ok = 0;
+      if (s.cnt[other] == 0 || !(mws_pair_known(pairs, other, rp) ||
+                                 (min(s.cnt[other], s.cnt[rp]) <= MWS_NESTED_MAX && mws_mutex_between(s, pairs, other, rp)))) ok = 0;
   }
   return ok;
 }
@@ -196,7 +220,7 @@ __device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target
 
 __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys, const unsigned* count, const int* offsets, MwsState s,
                                                                 u64* claim, u64* pairs, uint4* win0, uint4* win1, int2* ops, MwsCtl* ctl,
-                                                                int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap) {
+                                                                int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap, unsigned wmul) {
   __shared__ int lin[64];
   if (threadIdx.x < n_off && threadIdx.x < 64)
     lin[threadIdx.x] = (offsets[3 * threadIdx.x] * Y + offsets[3 * threadIdx.x + 1]) * X + offsets[3 * threadIdx.x + 2];
@@ -209,12 +233,13 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
   for (unsigned round = 1;; ++round) {
     // fresh edges this round: top the window up to ~2 entries per thread (the survivors already hold the earliest pending
     // edge, so progress never depends on new ones; a window full of blocked edges is re-examined every round, so keep it small)
-    unsigned want = nsurv < 2 * T ? 2 * T - nsurv : 0;
+    unsigned want = nsurv < wmul * T ? wmul * T - nsurv : 0;
     if (want > cap - nsurv) want = cap - nsurv;
     if (want > ne - next) want = ne - next;
     const unsigned n = nsurv + want;
     if (n == 0) break;
     const u64 tag = (u64)round << 32;
+    const u64 c0 = wall_clock64();
     // ---- phase A
     for (unsigned i = tid; i < n; i += T) {
       uint4 e;
@@ -239,6 +264,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       win[i] = e;
     }
     mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
+    const u64 c1 = wall_clock64();
     // ---- phase B
     unsigned* surv = &ctl->surv[round & 1];
     unsigned* nops = &ctl->nops[round & 1];
@@ -284,6 +310,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       }
     }
     mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
+    const u64 c2 = wall_clock64();
     const unsigned ns2 = __hip_atomic_load(surv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned no = __hip_atomic_load(nops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     next += want;
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       }
       mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
     }
+    if (tid == 0) { ctl->t[0] += c1 - c0; ctl->t[1] += c2 - c1; ctl->t[2] += wall_clock64() - c2; ctl->visits += n; }
     if (ns2 == n || round > (1u << 23)) {  // no edge retired although the earliest one always can: never expected; leave instead of spinning
       if (tid == 0) ctl->stalled = 1;
       break;
@@ -339,7 +367,7 @@ __global__ void mws_label_kernel(MwsState s, const unsigned char* mask, const in
 }
 
 #define MWS_WIN_CAP (1u << 20)
-#define MWS_MAX_WGS 32
+#define MWS_MAX_WGS 128
 struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_pairs, off_ops, off_win, off_keys2, off_cnt, off_state, off_pool, off_first, off_flags, off_rank, off_tmp, tmp_bytes, total; };
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
@@ -406,7 +434,7 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
   hipLaunchKernelGGL(mws_init_kernel, dim3(blocks), dim3(256), 0, st, S, first, flags, q.N);
   RG_CHECK_LAUNCH();
   if (p->n_offsets > 64) RG_FAIL(RG_ERR_UNSUPPORTED, "mws: at most 64 offsets");
-  hipLaunchKernelGGL(mws_edges_kernel, dim3((unsigned)((q.N + 255) / 256)), dim3(256), 0, st, affs, offsets, mask, keys, count, Z, Y, X, p->n_offsets,
+  hipLaunchKernelGGL(mws_edges_kernel, dim3((unsigned)((q.N + MWS_EDGE_THREADS - 1) / MWS_EDGE_THREADS)), dim3(MWS_EDGE_THREADS), 0, st, affs, offsets, mask, keys, count, Z, Y, X, p->n_offsets,
                      p->n_attractive, p->strides[0], p->strides[1], p->strides[2]);
   RG_CHECK_LAUNCH();
   size_t tb = q.tmp_bytes;
@@ -427,9 +455,10 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
     MwsCtl* ctl = (MwsCtl*)(w + q.off_cnt + 64);
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
-    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes;
+    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
+    if (const char* e = getenv("RG_MWS_WMUL")) { const int v = atoi(e); if (v >= 1 && (unsigned)v * wgs * MWS_THREADS <= cap) wmul = v; }
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
-    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap};
+    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul};
     rg_set_kernel_name("mws_rounds_kernel");
     rg_prof_mark(st);
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
@@ -439,7 +468,8 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
       MwsCtl h; unsigned ne = 0;
       hipStreamSynchronize(st);
       hipMemcpy(&h, ctl, sizeof(h), hipMemcpyDeviceToHost); hipMemcpy(&ne, count, 4, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[mws] N=%ld edges=%u rounds=%u pool=%u stalled=%u wgs=%d\n", q.N, ne, h.rounds, h.pool_used, h.stalled, wgs);
+      fprintf(stderr, "[mws] N=%ld edges=%u rounds=%u pool=%u stalled=%u wgs=%d visits=%llu  A %.2f ms  B %.2f ms  C %.2f ms\n", q.N, ne, h.rounds,
+              h.pool_used, h.stalled, wgs, h.visits, h.t[0] * 1e-5, h.t[1] * 1e-5, h.t[2] * 1e-5);
     }
   }
   hipLaunchKernelGGL(mws_first_kernel, dim3(blocks), dim3(256), 0, st, S, mask, first, q.N);

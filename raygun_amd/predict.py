@@ -12,6 +12,9 @@ per-block normalise -> forward -> crop -> convert -> write).
     kernel (rg_copy_convert), the forward runs under no_grad in bf16, outputs are cropped, then either kept as float32 or
     scaled by iinfo(dtype).max and clamped for integer destinations (worker.py:133-149).
 """
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -93,6 +96,7 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
         model.eval()
     src_t = source if resident else torch.from_numpy(np.ascontiguousarray(source))
     n_done = 0
+    drain = None
     for bi in mine:
         wz, wy, wx = blocks[bi]
         rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
@@ -118,7 +122,92 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
             if tuple(o.shape[-3:]) != tuple(write):
                 off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
                 o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
-            arr = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], resident)
-            dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = arr
+            if resident:
+                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
+            elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
+                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
+            else:  # convert on the GPU, then let the drain thread download and scatter while the next block computes
+                if drain is None:
+                    drain = _Drain(dev)
+                drain.put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
+                          (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
         n_done += 1
+    if drain is not None:
+        drain.close()
     return destinations, n_done
+
+
+class _Drain:
+    """Host side of the block runner: one thread that downloads finished blocks through two pinned staging buffers on its own
+    HIP stream and scatters them into the destination arrays (a multi-threaded torch CPU copy), so PCIe and the host memory
+    traffic overlap the next block's forward pass.  At most two blocks are in flight."""
+
+    def __init__(self, dev):
+        import queue
+        import threading
+        self.dev, self.q, self.err = dev, queue.Queue(maxsize=2), None
+        self.stream = torch.cuda.Stream(dev)
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        self.stage, self.turn, self.stats = {}, 0, [0.0, 0.0, 0.0]
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def put(self, gpu, dest, where):
+        if self.err is not None:
+            raise self.err
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        gpu.record_stream(self.stream)
+        t0 = time.perf_counter()
+        self.q.put((gpu, ev, dest, where))
+        self.stats[2] += time.perf_counter() - t0
+
+    def _run(self):
+        try:
+            with torch.cuda.device(self.dev):
+                while True:
+                    item = self.q.get()
+                    if item is None:
+                        return
+                    gpu, ev, dest, where = item
+                    key = (gpu.dtype, gpu.numel(), self.turn & 1)
+                    self.turn += 1
+                    if key not in self.stage:
+                        self.stage[key] = torch.empty(gpu.numel(), dtype=gpu.dtype).pin_memory()
+                    host = self.stage[key].view(gpu.shape)
+                    t0 = time.perf_counter()
+                    with torch.cuda.stream(self.stream):
+                        self.stream.wait_event(ev)
+                        host.copy_(gpu, non_blocking=True)
+                    self.stream.synchronize()
+                    t1 = time.perf_counter()
+                    self._scatter(dest, where, host.numpy())
+                    self.stats[0] += t1 - t0; self.stats[1] += time.perf_counter() - t1
+        except BaseException as e:  # surfaced by the next put() / close()
+            self.err = e
+            while True:
+                if self.q.get() is None:
+                    return
+
+    def _scatter(self, dest, where, block):
+        """dest[where] = block, split over a few threads (numpy releases the GIL inside the copies; a fresh destination is
+        also page-faulted in here, which is what dominates a first pass)."""
+        if block.ndim == 3:
+            z = block.shape[0]
+            parts = [(dest, (slice(where[1].start + i0, where[1].start + min(i0 + 16, z)), where[2], where[3]), block[i0:i0 + 16]) for i0 in range(0, z, 16)]
+        else:
+            parts = [(dest, (c,) + tuple(where[1:]), block[c]) for c in range(block.shape[0])]
+
+        def one(p):
+            p[0][p[1]] = p[2]
+        list(self.pool.map(one, parts))
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+        self.pool.shutdown()
+        if os.environ.get("RAYGUN_AMD_DRAIN_STATS"):
+            print(f"[drain] download {self.stats[0]:.3f} s, scatter {self.stats[1]:.3f} s, producer blocked {self.stats[2]:.3f} s", flush=True)
+        if self.err is not None:
+            raise self.err
