@@ -15,7 +15,7 @@ static NormPlan norm_plan(const CL5& t) {
   int x = 1; while (x < G8 && x < 32) x <<= 1;
   p.gx = x; p.gy = 256 / x;
   const long nvox = (long)t.D * t.H * t.W;
-  long want = 512 / (t.N > 0 ? t.N : 1); if (want < 8) want = 8;
+  long want = 1024 / (t.N > 0 ? t.N : 1); if (want < 8) want = 8;
   long v = (nvox + want - 1) / want; if (v < p.gy * 4) v = p.gy * 4;
   p.vpb = (int)v; p.nblk = (int)((nvox + v - 1) / v);
   return p;
@@ -56,20 +56,35 @@ __global__ void norm_reduce_kernel(CL5 x, CL5 y, CL5 gy, const float* mr, float*
     }
   }
   if (active) {
-    for (long v = v0 + threadIdx.y; v < v1; v += GY) {
-      const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, (unsigned)v, dense) + grp * 8);
-      if (MODE == 0) {
+    // NU voxels in flight per thread: all their loads are issued before the first use (the streams are latency-bound otherwise)
+    constexpr int NU = 4;
+    for (long vb = v0 + threadIdx.y; vb < v1; vb += (long)GY * NU) {
+      bf16x8 xv[NU], gv[NU], yv[NU];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float f = bf2f((bf16_t)xv[k]); s0[k] += f; s1[k] += f * f; }
-      } else {
-        const bf16x8 gv = *(const bf16x8*)(gy.p + vox_off(gy, n, (unsigned)v, dense) + grp * 8);
-        bf16x8 yv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + vox_off(y, n, (unsigned)v, dense) + grp * 8);
+      for (int u = 0; u < NU; ++u) {
+        const long v = vb + (long)u * GY;
+        const bool in = v < v1;
+        xv[u] = gv[u] = yv[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (in) {
+          xv[u] = *(const bf16x8*)(x.p + vox_off(x, n, (unsigned)v, dense) + grp * 8);
+          if (MODE == 1) {
+            gv[u] = *(const bf16x8*)(gy.p + vox_off(gy, n, (unsigned)v, dense) + grp * 8);
+            if (act != RG_ACT_NONE) yv[u] = *(const bf16x8*)(y.p + vox_off(y, n, (unsigned)v, dense) + grp * 8);
+          }
+        }
+      }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float g = bf2f((bf16_t)gv[k]) * act_bwd_from_y(bf2f((bf16_t)yv[k]), act, slope);
-          const float xh = (bf2f((bf16_t)xv[k]) - mean[k]) * rstd[k];
-          s0[k] += g; s1[k] += g * xh;
+      for (int u = 0; u < NU; ++u) {
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float f = bf2f((bf16_t)xv[u][k]); s0[k] += f; s1[k] += f * f; }  // out-of-range voxels were zero-filled
+        } else if (vb + (long)u * GY < v1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float g = bf2f((bf16_t)gv[u][k]) * act_bwd_from_y(bf2f((bf16_t)yv[u][k]), act, slope);
+            const float xh = (bf2f((bf16_t)xv[u][k]) - mean[k]) * rstd[k];
+            s0[k] += g; s1[k] += g * xh;
+          }
         }
       }
     }
@@ -130,18 +145,31 @@ __global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, int ac
   const unsigned nvox = (unsigned)(y.D * y.H * y.W);
   const unsigned v0 = blockIdx.x * (unsigned)vpb;
   unsigned v1 = v0 + (unsigned)vpb; if (v1 > nvox) v1 = nvox;
-  for (unsigned v = v0 + threadIdx.y; v < v1; v += blockDim.y) {
-    const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
-    bf16x8 rv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (has_res) rv = *(const bf16x8*)(res.p + vox_off(res, n, v, dense) + grp * 8);
-    bf16x8 o;
+  constexpr int NU = 4;  // voxels in flight per thread
+  for (unsigned vb = v0 + threadIdx.y; vb < v1; vb += blockDim.y * NU) {
+    bf16x8 xv[NU], rv[NU];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float val = 0.f;
-      if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[k]) - m[k]) * r[k], act, slope) + bf2f((bf16_t)rv[k]);
-      o[k] = (short)f2bf(val);
+    for (int u = 0; u < NU; ++u) {
+      const unsigned v = vb + u * blockDim.y;
+      xv[u] = rv[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (v < v1) {
+        xv[u] = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
+        if (has_res) rv[u] = *(const bf16x8*)(res.p + vox_off(res, n, v, dense) + grp * 8);
+      }
     }
-    *(bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8) = o;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const unsigned v = vb + u * blockDim.y;
+      if (v >= v1) break;
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float val = 0.f;
+        if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[u][k]) - m[k]) * r[k], act, slope) + bf2f((bf16_t)rv[u][k]);
+        o[k] = (short)f2bf(val);
+      }
+      *(bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8) = o;
+    }
   }
 }
 // launch shape shared by apply / bwd: ~2048 workgroups of (gx channel groups) x (256/gx voxels in flight)
@@ -186,23 +214,36 @@ __global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, c
   const unsigned nvox = (unsigned)(gx.D * gx.H * gx.W);
   const unsigned v0 = blockIdx.x * (unsigned)vpb;
   unsigned v1 = v0 + (unsigned)vpb; if (v1 > nvox) v1 = nvox;
-  for (unsigned v = v0 + threadIdx.y; v < v1; v += blockDim.y) {
-    const bf16x8 xv = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
-    const bf16x8 gv = *(const bf16x8*)(gy.p + vox_off(gy, n, v, dense) + grp * 8);
-    bf16x8 yv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (act != RG_ACT_NONE) yv = *(const bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8);
-    bf16x8 o;
+  constexpr int NU = 4;  // voxels in flight per thread
+  for (unsigned vb = v0 + threadIdx.y; vb < v1; vb += blockDim.y * NU) {
+    bf16x8 xv[NU], gv[NU], yv[NU];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float val = 0.f;
-      if (grp * 8 + k < x.C) {
-        const float g = bf2f((bf16_t)gv[k]) * act_bwd_from_y(bf2f((bf16_t)yv[k]), act, slope);
-        const float xh = (bf2f((bf16_t)xv[k]) - m[k]) * r[k];
-        val = r[k] * (g - g0[k] - xh * g1[k]);
+    for (int u = 0; u < NU; ++u) {
+      const unsigned v = vb + u * blockDim.y;
+      xv[u] = gv[u] = yv[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (v < v1) {
+        xv[u] = *(const bf16x8*)(x.p + vox_off(x, n, v, dense) + grp * 8);
+        gv[u] = *(const bf16x8*)(gy.p + vox_off(gy, n, v, dense) + grp * 8);
+        if (act != RG_ACT_NONE) yv[u] = *(const bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8);
       }
-      o[k] = (short)f2bf(val);
     }
-    *(bf16x8*)(gx.p + vox_off(gx, n, v, dense) + grp * 8) = o;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const unsigned v = vb + u * blockDim.y;
+      if (v >= v1) break;
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float val = 0.f;
+        if (grp * 8 + k < x.C) {
+          const float g = bf2f((bf16_t)gv[u][k]) * act_bwd_from_y(bf2f((bf16_t)yv[u][k]), act, slope);
+          const float xh = (bf2f((bf16_t)xv[u][k]) - m[k]) * r[k];
+          val = r[k] * (g - g0[k] - xh * g1[k]);
+        }
+        o[k] = (short)f2bf(val);
+      }
+      *(bf16x8*)(gx.p + vox_off(gx, n, v, dense) + grp * 8) = o;
+    }
   }
 }
 extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const rg_tensor* y, const rg_tensor* gy,

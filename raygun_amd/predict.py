@@ -71,16 +71,20 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
     model: callable taking a (1,1,z,y,x) tensor and returning a tensor or tuple of tensors (worker.py:116-119).
     Returns (list of destination ndarrays, number of blocks this rank processed).  Destinations are zero where no block
     wrote (borders; other ranks' blocks when world > 1).  A `source` that is a tensor already on the GPU keeps the whole
-    pipeline there: the destinations are device tensors and nothing crosses PCIe."""
+    pipeline there: the destinations are device tensors and nothing crosses PCIe.  Any other array-like with `.shape`,
+    `.dtype` and slice reads (a numpy array, a `zarrio.Array`) is read block by block, one block ahead of the GPU; given
+    `destinations` (numpy arrays or `zarrio.Array`s) are written in place.  On-disk chunks are only written whole when the
+    dataset's chunk shape equals the write ROI (what `zarrio.prepare_ds(..., write_size=...)` lays down)."""
     resident = torch.is_tensor(source) and source.is_cuda
     if resident:
         src_np_dtype = np.dtype(str(source.dtype).replace("torch.", ""))
         if device is None:
             device = source.device
     else:
-        source = np.asarray(source)
-        src_np_dtype = source.dtype
-    if source.ndim != 3:
+        if not (hasattr(source, "shape") and hasattr(source, "dtype") and hasattr(source, "__getitem__")):
+            source = np.asarray(source)
+        src_np_dtype = np.dtype(source.dtype)
+    if len(source.shape) != 3:
         raise ValueError("source must be a (Z, Y, X) volume")
     if not np.issubdtype(src_np_dtype, np.integer):
         raise TypeError("source must be an integer volume (worker.py:109-110 normalises with np.iinfo)")
@@ -94,13 +98,28 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
         scale, shift = scale * scaleShift_input[0], shift * scaleShift_input[0] + scaleShift_input[1]
     if hasattr(model, "eval"):
         model.eval()
-    src_t = source if resident else torch.from_numpy(np.ascontiguousarray(source))
-    n_done = 0
-    drain = None
-    for bi in mine:
+    def fetch(bi):  # host side of one block: slice (or chunk reads + decompression), contiguous, pinned
         wz, wy, wx = blocks[bi]
         rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
-        blk = src_t[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]].to(dev, non_blocking=True)[None, None]
+        a = np.ascontiguousarray(source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]])
+        return torch.from_numpy(a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))).pin_memory()
+
+    n_done = 0
+    drain = None
+    ahead = None
+    if not resident and len(mine):
+        from concurrent.futures import ThreadPoolExecutor
+        reader = ThreadPoolExecutor(max_workers=1)
+        ahead = reader.submit(fetch, mine[0])
+    for k, bi in enumerate(mine):
+        wz, wy, wx = blocks[bi]
+        rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
+        if resident:
+            blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
+        else:
+            host = ahead.result()
+            ahead = reader.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
+            blk = host.to(dev, non_blocking=True)[None, None]
         if blk.dtype not in (torch.uint8,):
             blk = blk.float()
         x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
@@ -134,7 +153,38 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
         n_done += 1
     if drain is not None:
         drain.close()
+    if not resident and len(mine):
+        reader.shutdown()
     return destinations, n_done
+
+
+def predict_zarr(model, source_path, source_dataset, dest_path=None, output_ds=None, out_specs=None, input_shape=None,
+                 output_shape=None, read_size=None, crop=0, ndims=3, scaleShift_input=None, out_channels=None, rank=None,
+                 world=None, device=None):
+    """The on-disk flow of raygun.predict (predict.py:70,111-125,154-164) without daisy / zarr: open the source dataset, lay
+    down one destination dataset per model output — same extent, voxel size and offset as the source, chunked by the write
+    ROI, dtype from `out_specs[name]["dtype"]` (default: the source's, as the reference does), a channel axis when the output
+    has more than one channel — and predict into them block by block.  Returns the destination arrays."""
+    from . import zarrio
+    src = zarrio.open_ds(source_path, source_dataset)
+    dest_path = dest_path or source_path
+    read, write, _ = roi_geometry(ndims, input_shape, output_shape, read_size, crop)
+    names = list(output_ds) if output_ds is not None else [f"{source_dataset}_pred"]
+    n_ch = list(out_channels) if out_channels is not None else [None] * len(names)
+    dests = []
+    if (rank or 0) == 0:
+        for name, c in zip(names, n_ch):
+            spec = dict(dtype=src.dtype, num_channels=c if c and c > 1 else None)
+            spec.update((out_specs or {}).get(name, {}))
+            dests.append(zarrio.prepare_ds(dest_path, name, src.shape, src.voxel_size, spec["dtype"], write_size=write,
+                                           num_channels=spec["num_channels"], offset=src.offset))
+    if world and world > 1:
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+        dests = [zarrio.open_ds(dest_path, name, "a") for name in names]
+    predict_volume(model, src, input_shape, output_shape, read_size, crop, ndims, scaleShift_input,
+                   [d.dtype for d in dests], out_channels, rank, world, device, destinations=dests)
+    return dests
 
 
 class _Drain:
@@ -192,7 +242,11 @@ class _Drain:
 
     def _scatter(self, dest, where, block):
         """dest[where] = block, split over a few threads (numpy releases the GIL inside the copies; a fresh destination is
-        also page-faulted in here, which is what dominates a first pass)."""
+        also page-faulted in here, which is what dominates a first pass).  Chunked on-disk destinations are written by this
+        one thread (a chunk must not be read-modified-written from two threads)."""
+        if not isinstance(dest, np.ndarray):
+            dest[tuple(slice(None) if w is Ellipsis else w for w in where) if dest.ndim == 4 else tuple(where[1:])] = block
+            return
         if block.ndim == 3:
             z = block.shape[0]
             parts = [(dest, (slice(where[1].start + i0, where[1].start + min(i0 + 16, z)), where[2], where[3]), block[i0:i0 + 16]) for i0 in range(0, z, 16)]

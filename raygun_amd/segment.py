@@ -6,9 +6,9 @@ rg_mws_segment (edge keys -> device radix sort -> wavefront-level union-find wit
 watershed + waterz agglomeration branch of segment.py (:46-136) is a different algorithm and out of scope
 (SURVEY.md §2 #13b): `segment(config)` with mutex=False raises.
 
-Volumes are taken from the config's zarr container when the `zarr` package is importable, or passed in memory
-(`affs=` keyword / config["affs"] as an ndarray or a .npy path) — the reference reads the whole array into RAM
-anyway (segment.py:183-186).
+Volumes are taken from the config's zarr container (the `zarr` package when importable, else raygun_amd.zarrio), or
+passed in memory (`affs=` keyword / config["affs"] as an ndarray or a .npy path) — the reference reads the whole array
+into RAM anyway (segment.py:183-186).
 """
 import ctypes as C
 import os
@@ -135,9 +135,8 @@ def mutex_segment(config_path, affs=None):
     if affs is None:
         try:
             import zarr
-        except ImportError as e:
-            raise RuntimeError("raygun_amd.mutex_segment: pass `affs=` (ndarray) or config['affs'] (.npy path); reading "
-                               "config['file'] needs the `zarr` package, which is not installed") from e
+        except ImportError:
+            from . import zarrio as zarr  # zarr v2 directory stores with stdlib codecs (see zarrio.py)
         f = zarr.open(seg_config["file"], "a")
         affs = f[seg_config["aff_ds"]][:]
     if not torch.is_tensor(affs):

@@ -1,0 +1,288 @@
+"""Minimal zarr (v2, directory store) reader / writer for the block runner and the segmenter — the data formats either side
+of the hot path.  The reference reaches its volumes through `daisy.open_ds` / `daisy.prepare_ds`
+(src/raygun/predict.py:70,111-125; torch/predict/worker.py:75,92) and `zarr.open` (src/raygun/segment.py:183,210-212);
+neither package is installed here, so this module restates the PUBLISHED zarr v2 storage spec (zarr-specs "v2.0":
+`.zarray` / `.zattrs` / `.zgroup` JSON, one file per chunk named by its grid index, edge chunks stored full-size, missing
+chunks = fill_value) — PARITY UNPINNED against the zarr package itself; `tests/test_zarrio.py` checks it against chunk files
+laid down by hand from the spec.
+
+Codecs: none, zlib, gzip, bz2, lzma (python stdlib).  Blosc — zarr's own default — needs numcodecs and raises a clear error.
+Filters are not supported.  N5 containers are not supported.
+"""
+import builtins
+import bz2
+import gzip
+import json
+import lzma
+import os
+import shutil
+import zlib
+
+import numpy as np
+
+_fopen = builtins.open  # this module defines its own open() (zarr.open)
+
+_CODECS = {
+    "zlib": (lambda b, cfg: zlib.compress(b, cfg.get("level", 1)), lambda b: zlib.decompress(b)),
+    "gzip": (lambda b, cfg: gzip.compress(b, cfg.get("level", 1)), lambda b: gzip.decompress(b)),
+    "bz2": (lambda b, cfg: bz2.compress(b, cfg.get("level", 1)), lambda b: bz2.decompress(b)),
+    "lzma": (lambda b, cfg: lzma.compress(b), lambda b: lzma.decompress(b)),
+}
+
+
+def _write_json(path, obj):
+    tmp = path + ".tmp"
+    with _fopen(tmp, "w") as f:
+        json.dump(obj, f, indent=4)
+    os.replace(tmp, path)
+
+
+class Attributes(dict):
+    """`.zattrs` as a dict that writes itself back on every change (zarr's `array.attrs[...] = ...`)."""
+
+    def __init__(self, path, writable):
+        self._path, self._writable = path, writable
+        if os.path.exists(path):
+            with _fopen(path) as f:
+                super().update(json.load(f))
+
+    def _flush(self):
+        if not self._writable:
+            raise PermissionError("zarr container opened read-only")
+        _write_json(self._path, dict(self))
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        self._flush()
+
+    def update(self, *a, **kw):
+        super().update(*a, **kw)
+        self._flush()
+
+
+class Array:
+    def __init__(self, path, mode="r"):
+        self.path, self.mode = path, mode
+        with _fopen(os.path.join(path, ".zarray")) as f:
+            m = json.load(f)
+        if m.get("zarr_format") != 2:
+            raise ValueError(f"{path}: only zarr_format 2 is supported")
+        if m.get("filters"):
+            raise NotImplementedError(f"{path}: filters are not supported")
+        self.shape = tuple(int(v) for v in m["shape"])
+        self.chunks = tuple(int(v) for v in m["chunks"])
+        self.dtype = np.dtype(m["dtype"])
+        self.order = m.get("order", "C")
+        self.fill_value = m.get("fill_value")
+        self.compressor = m.get("compressor")
+        self.sep = m.get("dimension_separator", ".")
+        if self.compressor is not None and self.compressor.get("id") not in _CODECS:
+            raise NotImplementedError(f"{path}: compressor {self.compressor.get('id')!r} is not available here "
+                                      f"(supported: none, {', '.join(sorted(_CODECS))}); re-encode the dataset or install numcodecs")
+        self.attrs = Attributes(os.path.join(path, ".zattrs"), mode != "r")
+        self.ndim = len(self.shape)
+
+    # -- chunk level
+    def _chunk_path(self, idx):
+        return os.path.join(self.path, self.sep.join(str(i) for i in idx)) if self.sep == "." else os.path.join(self.path, *[str(i) for i in idx])
+
+    def _fill(self):
+        fv = self.fill_value
+        if fv is None:
+            return np.zeros((), self.dtype)
+        if isinstance(fv, str):  # "NaN" / "Infinity" / "-Infinity"
+            fv = {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}.get(fv, fv)
+        return np.array(fv).astype(self.dtype)
+
+    def _read_chunk(self, idx):
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            return None
+        with _fopen(p, "rb") as f:
+            raw = f.read()
+        if self.compressor is not None:
+            raw = _CODECS[self.compressor["id"]][1](raw)
+        a = np.frombuffer(raw, dtype=self.dtype)
+        if a.size != int(np.prod(self.chunks)):
+            raise ValueError(f"{p}: chunk holds {a.size} items, expected {int(np.prod(self.chunks))}")
+        return a.reshape(self.chunks, order=self.order)
+
+    def _write_chunk(self, idx, data):
+        p = self._chunk_path(idx)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        raw = np.asarray(data, dtype=self.dtype).tobytes(order=self.order)
+        if self.compressor is not None:
+            raw = _CODECS[self.compressor["id"]][0](raw, self.compressor)
+        tmp = p + f".{os.getpid()}.tmp"
+        with _fopen(tmp, "wb") as f:
+            f.write(raw)
+        os.replace(tmp, p)
+
+    # -- region level
+    def _region(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = [k is Ellipsis for k in key].index(True)
+            key = key[:i] + (slice(None),) * (self.ndim - (len(key) - 1)) + key[i + 1:]
+        key = key + (slice(None),) * (self.ndim - len(key))
+        if len(key) != self.ndim:
+            raise IndexError(f"too many indices for a {self.ndim}-d array")
+        lo, hi, squeeze = [], [], []
+        for k, n in zip(key, self.shape):
+            if isinstance(k, (int, np.integer)):
+                k = int(k) + (n if k < 0 else 0)
+                if not 0 <= k < n:
+                    raise IndexError("index out of range")
+                lo.append(k); hi.append(k + 1); squeeze.append(True)
+            elif isinstance(k, slice):
+                a, b, st = k.indices(n)
+                if st != 1:
+                    raise NotImplementedError("strided selections are not supported")
+                lo.append(a); hi.append(max(a, b)); squeeze.append(False)
+            else:
+                raise TypeError(f"unsupported index {k!r}")
+        return lo, hi, squeeze
+
+    def _chunk_ranges(self, lo, hi):
+        import itertools
+        ranges = [range(a // c, (b - 1) // c + 1) if b > a else range(0) for a, b, c in zip(lo, hi, self.chunks)]
+        return itertools.product(*ranges)
+
+    def __getitem__(self, key):
+        lo, hi, squeeze = self._region(key)
+        out = np.empty([b - a for a, b in zip(lo, hi)], dtype=self.dtype)
+        fill = self._fill()
+        for idx in self._chunk_ranges(lo, hi):
+            c0 = [i * c for i, c in zip(idx, self.chunks)]
+            src = tuple(slice(max(a, o) - o, min(b, o + c) - o) for a, b, o, c in zip(lo, hi, c0, self.chunks))
+            dst = tuple(slice(max(a, o) - a, min(b, o + c) - a) for a, b, o, c in zip(lo, hi, c0, self.chunks))
+            ch = self._read_chunk(idx)
+            out[dst] = fill if ch is None else ch[src]
+        return out[tuple(0 if s else slice(None) for s in squeeze)]
+
+    def __setitem__(self, key, value):
+        if self.mode == "r":
+            raise PermissionError("zarr container opened read-only")
+        lo, hi, squeeze = self._region(key)
+        shape = [b - a for a, b in zip(lo, hi)]
+        value = np.asarray(value, dtype=self.dtype)
+        kept = [n for s, n in zip(squeeze, shape) if not s]
+        if any(squeeze) and value.ndim <= len(kept):  # integer-indexed axes come back as length-1 axes
+            value = np.broadcast_to(value, kept).reshape(shape)
+        value = np.broadcast_to(value, shape)
+        for idx in self._chunk_ranges(lo, hi):
+            c0 = [i * c for i, c in zip(idx, self.chunks)]
+            src = tuple(slice(max(a, o) - a, min(b, o + c) - a) for a, b, o, c in zip(lo, hi, c0, self.chunks))
+            dst = tuple(slice(max(a, o) - o, min(b, o + c) - o) for a, b, o, c in zip(lo, hi, c0, self.chunks))
+            whole = all(s.start == 0 and s.stop == c for s, c in zip(dst, self.chunks))
+            if whole:
+                ch = value[src]
+            else:  # read-modify-write; cells of an edge chunk beyond the array bounds keep whatever they held
+                ch = self._read_chunk(idx)
+                ch = np.full(self.chunks, self._fill(), dtype=self.dtype) if ch is None else ch.copy()
+                ch[dst] = value[src]
+            self._write_chunk(idx, ch)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[...]
+        return a if dtype is None else a.astype(dtype)
+
+
+class Group:
+    def __init__(self, path, mode="r"):
+        self.path, self.mode = path, mode
+        self.attrs = Attributes(os.path.join(path, ".zattrs"), mode != "r")
+
+    def __contains__(self, name):
+        p = os.path.join(self.path, name)
+        return os.path.exists(os.path.join(p, ".zarray")) or os.path.exists(os.path.join(p, ".zgroup"))
+
+    def __getitem__(self, name):
+        p = os.path.join(self.path, name)
+        if os.path.exists(os.path.join(p, ".zarray")):
+            return Array(p, self.mode)
+        if os.path.exists(os.path.join(p, ".zgroup")):
+            return Group(p, self.mode)
+        raise KeyError(name)
+
+    def create_dataset(self, name, shape, chunks=None, dtype="f4", compressor="default", fill_value=0, overwrite=False,
+                       dimension_separator="."):
+        if self.mode == "r":
+            raise PermissionError("zarr container opened read-only")
+        p = os.path.join(self.path, name)
+        if os.path.exists(p):
+            if not overwrite:
+                raise FileExistsError(p)
+            shutil.rmtree(p)
+        # intermediate groups
+        q = self.path
+        for part in os.path.normpath(name).split(os.sep)[:-1]:
+            q = os.path.join(q, part)
+            os.makedirs(q, exist_ok=True)
+            if not os.path.exists(os.path.join(q, ".zgroup")):
+                _write_json(os.path.join(q, ".zgroup"), {"zarr_format": 2})
+        os.makedirs(p)
+        shape = tuple(int(v) for v in shape)
+        if chunks is None:
+            chunks = tuple(min(s, 64) for s in shape)
+        if compressor == "default":
+            compressor = {"id": "zlib", "level": 1}
+        meta = {"zarr_format": 2, "shape": list(shape), "chunks": [int(c) for c in chunks], "dtype": np.dtype(dtype).str,
+                "compressor": compressor, "fill_value": fill_value, "order": "C", "filters": None}
+        if dimension_separator != ".":
+            meta["dimension_separator"] = dimension_separator
+        _write_json(os.path.join(p, ".zarray"), meta)
+        return Array(p, self.mode)
+
+    def __setitem__(self, name, value):
+        """`f[name] = ndarray` as segment.py:210 does: (re)creates the dataset and stores the array."""
+        value = np.asarray(value)
+        a = self.create_dataset(name, value.shape, dtype=value.dtype, overwrite=True)
+        a[...] = value
+
+
+def open(path, mode="r"):  # noqa: A001  (mirrors zarr.open)
+    """zarr.open(path, mode): a Group or an Array.  mode 'r' read-only, 'a' read/write (created when missing), 'w' recreate."""
+    if mode == "w" and os.path.exists(path):
+        shutil.rmtree(path)
+    if not os.path.exists(path):
+        if mode == "r":
+            raise FileNotFoundError(path)
+        os.makedirs(path)
+        _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+    if os.path.exists(os.path.join(path, ".zarray")):
+        return Array(path, mode)
+    if not os.path.exists(os.path.join(path, ".zgroup")):
+        if mode == "r":
+            raise ValueError(f"{path} is not a zarr v2 container (no .zgroup / .zarray)")
+        _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+    return Group(path, mode)
+
+
+def open_ds(filename, ds_name, mode="r"):
+    """daisy.open_ds for zarr containers: the Array, with `.voxel_size` and `.offset` (world units) from its attributes
+    ('resolution' / 'offset', defaults 1 and 0 per spatial axis)."""
+    a = open(filename, mode)[ds_name]
+    nsp = min(3, a.ndim)
+    a.voxel_size = tuple(int(v) for v in a.attrs.get("resolution", (1,) * nsp))
+    a.offset = tuple(int(v) for v in a.attrs.get("offset", (0,) * nsp))
+    return a
+
+
+def prepare_ds(filename, ds_name, total_shape, voxel_size, dtype, write_size=None, num_channels=None, offset=None, delete=True,
+               compressor="default"):
+    """daisy.prepare_ds (predict.py:111-125): a fresh dataset covering `total_shape` voxels (+ a leading channel axis when
+    num_channels is given), chunked by the write ROI, carrying 'resolution' and 'offset' attributes."""
+    g = open(filename, "a")
+    shape = tuple(int(v) for v in total_shape)
+    chunks = tuple(int(v) for v in (write_size if write_size is not None else [min(s, 64) for s in shape]))
+    if num_channels is not None:
+        shape, chunks = (int(num_channels),) + shape, (int(num_channels),) + chunks
+    a = g.create_dataset(ds_name, shape, chunks=chunks, dtype=dtype, compressor=compressor, overwrite=delete)
+    a.attrs.update({"resolution": [int(v) for v in voxel_size], "offset": [int(v) for v in (offset if offset is not None else (0,) * len(voxel_size))]})
+    a.voxel_size, a.offset = tuple(int(v) for v in voxel_size), tuple(a.attrs["offset"])
+    return a

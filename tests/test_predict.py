@@ -63,3 +63,35 @@ def test_blockwise_equals_whole_volume():
     r8, _ = P.predict_volume(lambda t: torch.sigmoid(net(t)), torch.from_numpy(vol).to(dev), input_shape=[36] * 3, output_shape=[20] * 3,
                              out_dtypes=[np.uint8])
     assert r8[0].dtype == torch.uint8 and np.array_equal(r8[0].cpu().numpy(), d8[0])
+
+
+@pytest.mark.gpu
+def test_on_disk_flow_equals_in_memory(tmp_path):
+    """predict_zarr (zarr source -> zarr destinations chunked by the write ROI, offset / resolution carried over) gives the
+    same voxels as predict_volume on the in-memory array; then mutex_segment reads the predicted affinities from the
+    container and writes its labels next to them (segment.py:183-212)."""
+    from raygun_amd import zarrio
+    from raygun_amd.segment import mutex_segment
+    from raygun_amd.torch.networks import UNet
+    dev = torch.device("cuda")
+    net = UNet(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True, output_nc=20)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict(), 3))
+    net = net.to(dev)
+    model = lambda t: torch.sigmoid(net(t))
+    vol = (synth.uniform((60, 60, 60), 4, 0, 1) * 255).astype(np.uint8)
+    path = str(tmp_path / "vol.zarr")
+    raw = zarrio.prepare_ds(path, "volumes/raw", vol.shape, (4, 4, 4), np.uint8, write_size=(16, 16, 16), offset=(40, 0, 8), compressor=None)
+    raw[...] = vol
+    mem, n = P.predict_volume(model, vol, input_shape=[36] * 3, output_shape=[20] * 3, out_dtypes=[np.float32])
+    dests = P.predict_zarr(model, path, "volumes/raw", output_ds=["volumes/pred_affs"], out_specs={"volumes/pred_affs": {"dtype": np.float32}},
+                           input_shape=[36] * 3, output_shape=[20] * 3, out_channels=[20])
+    d = zarrio.open_ds(path, "volumes/pred_affs")
+    assert d.shape == (20, 60, 60, 60) and d.chunks == (20, 20, 20, 20) and d.voxel_size == (4, 4, 4) and d.offset == (40, 0, 8)
+    assert np.array_equal(d[...], mem[0]) and n == 8
+    seg = mutex_segment({"mutex": True, "file": path, "aff_ds": "volumes/pred_affs", "mask_thresh": 0.3})
+    f = zarrio.open(path)
+    stored = f["mutex_0.30"]
+    assert stored.dtype == np.uint64 and np.array_equal(stored[...], seg) and stored.attrs["offset"] == [40, 0, 8]
+    from oracle import mws as O
+    ww, m = O.prepare(mem[0].copy(), 3, 0.3, 1.0)
+    assert np.array_equal(seg, O.compute_mws_segmentation(ww, O.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m))
