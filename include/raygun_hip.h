@@ -152,6 +152,12 @@ int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream
  * x/y: bf16 channels-last, one of them 1 channel, the other KH*KW channels, equal batch and depth. */
 int rg_diag_spread(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, rg_stream s);
 int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, const float* bias, rg_stream s);
+/* Weights of `conv3d(cat([skip, nearest_upsample_x2(low)]), w)` (networks/UNet.py:338-351 followed by ConvPass, :70-95) split for
+ * the sub-pixel evaluation: wf = w[:, :cf] (O, cf, 3,3,3) and weff (8*O, C-cf, 2,2,2) = the 2^3 kernels the upsampled channels
+ * reduce to on the low-resolution tensor, one per output parity; both channels-last ([out][kd][kh][kw][in]) fp32.  w: fp32
+ * (O, C, 3,3,3), any strides.  _bwd: the adjoint — dw (strides as given) from the gradients of wf / weff (either may be NULL). */
+int rg_subpixel_weights(const rg_tensor* w, int cf, float* wf, float* weff, rg_stream s);
+int rg_subpixel_weights_bwd(const float* g_wf, const float* g_weff, const rg_tensor* dw, int cf, rg_stream s);
 
 /* ---- losses: value (fp32 scalar in out[0]) and gradient wrt pred in one pass.
  * kind 0: mean((p-t)^2) vs constant target  (GANLoss lsgan, losses/GANLoss.py:24-25,56-58)

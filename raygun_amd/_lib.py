@@ -64,6 +64,8 @@ _SIGS = {
     "rg_pad3d_bwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
     "rg_add": (C.c_int, [_T, _T, _T, C.c_void_p]),
     "rg_diag_spread": (C.c_int, [_T, _T, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rg_subpixel_weights": (C.c_int, [_T, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rg_subpixel_weights_bwd": (C.c_int, [C.c_void_p, C.c_void_p, _T, C.c_int, C.c_void_p]),
     "rg_diag_sum": (C.c_int, [_T, _T, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rg_loss_fwd_bwd": (C.c_int, [C.c_int, _T, _T, _T, C.c_float, C.c_float, _T, C.c_void_p, C.c_void_p]),
     "rg_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,

@@ -682,6 +682,87 @@ extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int k
   return RG_OK;
 }
 
+// ---------------------------------------------------------------------------- sub-pixel weights of conv(nearest_upsample_x2(.))
+// A 3^3 convolution applied to a nearest-x2 upsampled tensor is, per output parity p (one bit per dimension), a 2^3 convolution
+// on the low-resolution tensor: taps that fall on the same low-resolution cell s are summed —
+//   p = 0: s = 0 <- taps {0, 1}, s = 1 <- {2};   p = 1: s = 0 <- {0}, s = 1 <- {1, 2}      (per dimension)
+// forward: w (O, C, 3,3,3) any dense strides -> wf (O, cf, 3,3,3) = w[:, :cf]  and  weff (8*O, C-cf, 2,2,2), both channels-last
+// ([out][kd][kh][kw][in]); output channel of weff = ((pd*2+ph)*2+pw)*O + o.  backward: the adjoint, written in w's own strides.
+struct SubpixW { long so, sc, sd, sh, sw; int O, C, cf; };
+__device__ __forceinline__ void subpix_taps(int p, int s, int& t0, int& nt) { t0 = p == 0 ? (s == 0 ? 0 : 2) : (s == 0 ? 0 : 1); nt = (p == s) ? (p == 0 ? 2 : 2) : 1; }
+__global__ void subpixel_w_fwd_kernel(const float* w, SubpixW q, float* wf, float* weff) {
+  const int cg = q.C - q.cf;
+  const long n_eff = (long)8 * q.O * 8 * cg, n_f = (long)q.O * 27 * q.cf;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_eff + n_f; e += (long)gridDim.x * blockDim.x) {
+    if (e < n_eff) {
+      const int i = (int)(e % cg); long r = e / cg;
+      const int s = (int)(r % 8); r /= 8;
+      const int o = (int)(r % q.O), p = (int)(r / q.O);
+      int d0, nd, h0, nh, w0, nw;
+      subpix_taps((p >> 2) & 1, (s >> 2) & 1, d0, nd); subpix_taps((p >> 1) & 1, (s >> 1) & 1, h0, nh); subpix_taps(p & 1, s & 1, w0, nw);
+      const float* base = w + o * q.so + (long)(q.cf + i) * q.sc;
+      float acc = 0.f;
+      for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c)
+        acc += base[(d0 + a) * q.sd + (h0 + b) * q.sh + (w0 + c) * q.sw];
+      weff[e] = acc;
+    } else {
+      const long f = e - n_eff;
+      const int i = (int)(f % q.cf); long r = f / q.cf;
+      const int t = (int)(r % 27), o = (int)(r / 27);
+      wf[f] = w[o * q.so + (long)i * q.sc + (t / 9) * q.sd + ((t / 3) % 3) * q.sh + (t % 3) * q.sw];
+    }
+  }
+}
+// the (p, s) pairs of a dimension that contain tap t: t = 0: (0,0), (1,0);  t = 1: (0,0), (1,1);  t = 2: (0,1), (1,1)
+__global__ void subpixel_w_bwd_kernel(const float* gwf, const float* gweff, SubpixW q, float* dw) {
+  const int cg = q.C - q.cf;
+  const long n = (long)q.O * 27 * q.C;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % q.C); long r = e / q.C;
+    const int t = (int)(r % 27), o = (int)(r / 27);
+    const int td = t / 9, th = (t / 3) % 3, tw = t % 3;
+    float v = 0.f;
+    if (c < q.cf) { if (gwf) v = gwf[((long)o * 27 + t) * q.cf + c]; }
+    else if (gweff) {
+      const int i = c - q.cf;
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int k = 0; k < 2; ++k) {
+        // a-th pair of each dimension: p = a, s = (t == 0 ? 0 : t == 2 ? 1 : a)
+        const int pd = a, sd = td == 0 ? 0 : td == 2 ? 1 : a, ph = b, sh = th == 0 ? 0 : th == 2 ? 1 : b, pw = k, sw = tw == 0 ? 0 : tw == 2 ? 1 : k;
+        const int p = (pd << 2) | (ph << 1) | pw, s = (sd << 2) | (sh << 1) | sw;
+        v += gweff[(((long)p * q.O + o) * 8 + s) * cg + i];
+      }
+    }
+    dw[o * q.so + (long)c * q.sc + td * q.sd + th * q.sh + tw * q.sw] = v;
+  }
+}
+static int subpix_desc(const rg_tensor* w, int cf, SubpixW* q, const char* what) {
+  if (!w || !w->ptr || w->dtype != RG_F32 || w->rank != 5 || w->sizes[2] != 3 || w->sizes[3] != 3 || w->sizes[4] != 3)
+    { rg_set_error("%s: expected an fp32 (O, C, 3, 3, 3) weight", what); return RG_ERR_BAD_SHAPE; }
+  if (cf < 0 || cf >= w->sizes[1]) { rg_set_error("%s: split %d outside (0, %ld)", what, cf, (long)w->sizes[1]); return RG_ERR_BAD_SHAPE; }
+  q->so = w->strides[0]; q->sc = w->strides[1]; q->sd = w->strides[2]; q->sh = w->strides[3]; q->sw = w->strides[4];
+  q->O = (int)w->sizes[0]; q->C = (int)w->sizes[1]; q->cf = cf;
+  return RG_OK;
+}
+extern "C" int rg_subpixel_weights(const rg_tensor* w, int cf, float* wf, float* weff, rg_stream s) {
+  SubpixW q; int rc;
+  if ((rc = subpix_desc(w, cf, &q, "subpixel_weights"))) return rc;
+  if (!weff || (cf > 0 && !wf)) RG_FAIL(RG_ERR_BAD_SHAPE, "subpixel_weights: null output");
+  const long n = (long)64 * q.O * (q.C - q.cf) + (long)q.O * 27 * q.cf;
+  long blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(subpixel_w_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const float*)w->ptr, q, wf, weff);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_subpixel_weights_bwd(const float* g_wf, const float* g_weff, const rg_tensor* dw, int cf, rg_stream s) {
+  SubpixW q; int rc;
+  if ((rc = subpix_desc(dw, cf, &q, "subpixel_weights_bwd"))) return rc;
+  const long n = (long)q.O * 27 * q.C;
+  long blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(subpixel_w_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, g_wf, g_weff, q, (float*)dw->ptr);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
 // ---------------------------------------------------------------------------- fused Adam (torch.optim.Adam, no amsgrad)
 __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
                                          float bc1, float bc2_sqrt, float gscale) {

@@ -315,8 +315,8 @@ class FusedSequential(nn.Sequential):
     """nn.Sequential (same indices / state_dict keys / len) whose forward fuses
     [pad] conv [InstanceNorm] [activation]  into conv-epilogue / norm-apply kernels."""
 
-    def run(self, x, residual=None, upto=None):
-        mods = list(self)[:upto]
+    def run(self, x, residual=None, upto=None, start=0):
+        mods = list(self)[start:upto]
         i, n = 0, len(mods)
         while i < n:
             m = mods[i]

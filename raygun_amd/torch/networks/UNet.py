@@ -9,6 +9,7 @@ Differences that are deliberate:
   * 2-D / 4-D kernels are not built on this path yet: kernel rank 3 only.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -273,9 +274,40 @@ class UNet(nn.Module):
         else:
             g_in = self.l_down[i](f_left)
             gs_out = self.rec_forward(level - 1, g_in)
-            fs_right = [self.r_up[h][i](f_left, gs_out[h]) for h in range(self.num_heads)]
-            fs_out = [self.r_conv[h][i](fs_right[h]) for h in range(self.num_heads)]
+            fs_out = []
+            for h in range(self.num_heads):
+                fused = self._subpixel_up(self.r_up[h][i], self.r_conv[h][i], f_left, gs_out[h])
+                fs_out.append(fused if fused is not None else self.r_conv[h][i](self.r_up[h][i](f_left, gs_out[h])))
         return fs_out
+
+    @staticmethod
+    def _subpixel_up(up, rc, f_left, g_out):
+        """Nearest x2 upsample + crop + concat + the first 3x3x3 valid conv (+ activation) of the right ConvPass as
+        ops.upcat_conv3d (27 -> 8 taps on the upsampled channels), then the rest of the ConvPass.  None when the pattern does
+        not apply (other modes / factors / kernels, norm layers, residual passes, few upsampled channels) or with
+        RAYGUN_AMD_SUBPIXEL_UP=0."""
+        if os.environ.get("RAYGUN_AMD_SUBPIXEL_UP", "1") == "0" or not f_left.is_cuda:
+            return None
+        if up.mode != "nearest" or up.dims != 3 or up.scale_factor != (2, 2, 2) or rc.residual or str(rc.padding).lower() != "valid":
+            return None
+        mods = list(rc.conv_pass)
+        if len(mods) < 2 or not isinstance(mods[0], hipnn.Conv3d) or hipnn.act_of(mods[1]) is None:
+            return None
+        conv = mods[0]
+        if (tuple(conv.kernel_size) != (3, 3, 3) or tuple(conv.stride) != (1, 1, 1) or conv.groups != 1 or any(d != 1 for d in conv.dilation)
+                or conv.out_channels % 8 or g_out.shape[1] < 64 or g_out.dim() != 5):
+            return None
+        f_left, g_out = ops.enter(f_left), ops.enter(g_out)
+        up_shape = tuple(2 * v for v in g_out.shape[-3:])
+        target = up_shape
+        if up.crop_factor is not None:
+            target = up.target_shape(up_shape, tuple(up.crop_factor), [tuple(ks) for ks in up.next_conv_kernel_sizes])
+        if any(t < 3 for t in target) or any(a < t for a, t in zip(f_left.shape[-3:], target)):
+            return None
+        a = hipnn.act_of(mods[1])
+        with hipnn.scope():
+            y = ops.upcat_conv3d(f_left, g_out, target, conv.weight, conv.bias, a[0], a[1])
+            return rc.conv_pass.run(y, start=2)
 
     @hipnn.scoped
     def forward(self, x):

@@ -283,3 +283,33 @@ def test_fused_adam_refreshes_packed_forward_operand(cin, cout):
         fresh = ops.pack_weights(conv.weight.detach().clone(memory_format=torch.preserve_format), swap=0)
         assert torch.equal(cache[(0, (0, 0, 0), (1, 1, 1), None)].view(torch.int16), fresh.view(torch.int16))
         assert not torch.equal(before, conv.weight.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gs,fs,target", [((9, 9, 9), (20, 20, 20), (18, 18, 18)), ((9, 10, 11), (22, 21, 23), (16, 18, 20)),
+                                           ((8, 9, 8), (16, 17, 15), (13, 15, 11)), ((10, 9, 9), (24, 18, 20), (15, 17, 13))])
+def test_upcat_conv3d_equals_upsample_crop_concat_conv(gs, fs, target):
+    """ops.upcat_conv3d (27 -> 8 taps on the upsampled channels, depth-to-space) against the plain composition it replaces
+    (torch fp32 on bf16-exact operands): output and all four gradients, for even and odd crop offsets."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    cf, cg, cout = 16, 64, 24
+    torch.manual_seed(0)
+    f = torch.randn(1, cf, *fs, device=dev).bfloat16().float().requires_grad_()
+    g = torch.randn(1, cg, *gs, device=dev).bfloat16().float().requires_grad_()
+    w = (torch.randn(cout, cf + cg, 3, 3, 3, device=dev) * 0.05).bfloat16().float().requires_grad_()
+    b = torch.randn(cout, device=dev).requires_grad_()
+    up = torch.nn.functional.interpolate(g, scale_factor=2, mode="nearest")
+    x = torch.cat([ops.center_crop(f, target), ops.center_crop(up, target)], 1)
+    ref = torch.tanh(torch.nn.functional.conv3d(x, w, b))
+    go = torch.randn_like(ref).bfloat16().float()
+    rg = torch.autograd.grad(ref, (f, g, w, b), go)
+    got = ops.upcat_conv3d(f, g, target, w, b, "tanh")
+    assert tuple(got.shape) == tuple(ref.shape)
+    gg = torch.autograd.grad(got, (f, g, w, b), go.to(got.dtype) if got.dtype != go.dtype else go)
+    def close(a, r, tol):
+        a, r = a.float(), r.float()
+        assert (a - r).abs().max().item() <= tol * r.abs().max().item() + 1e-6, ((a - r).abs().max().item(), r.abs().max().item())
+    close(got, ref, 3e-2)  # pre-activations of magnitude ~10 rounded to bf16 twice
+    for a, r in zip(gg, rg):
+        close(a, r, 2e-2)
