@@ -145,6 +145,9 @@ int rg_pad3d_bwd(const rg_tensor* gy, const rg_tensor* gx, const int32_t pad[3],
 
 /* ---- residual add  y = a + b  (ResnetBlock3D.forward, ResNet.py:436-443) */
 int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, rg_stream s);
+/* y = a + zero_pad(b), b placed at `offset` inside a's extent (a may be NULL): the gradient of a tensor consumed whole by one op
+ * and centre-cropped by another (UNet skip connections, networks/UNet.py:97-106,327-336) in one pass. */
+int rg_add_pad(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, const int32_t offset[3], rg_stream s);
 
 /* ---- in-plane taps <-> channels of a one-channel volume (build-owned helpers of the 7^3 stem / composed tail,
  * networks/ResNet.py:283,338): spread  y[n,d,h,w][kh*KW+kw] = x[n,d,h+s*kh,w+s*kw][0] (0 outside x);

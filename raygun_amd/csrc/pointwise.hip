@@ -593,6 +593,43 @@ extern "C" int rg_add(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y
   return RG_OK;
 }
 
+// y = a + pad(b): b is a crop of a's extent starting at (od, oh, ow); outside it y = a.  The gradient of a tensor that is used
+// whole by one consumer and centre-cropped by another (the U-Net's skip connections) in ONE pass instead of zero-fill + copy + a
+// strided torch add.  a may be NULL (y = pad(b)).
+__global__ void add_pad_kernel(CL5 a, CL5 b, CL5 y, int od, int oh, int ow, int has_a) {
+  const int G8 = y.lanes / 8;
+  const long total = (long)y.N * y.D * y.H * y.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+    bf16x8 u = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}, v = u;
+    if (has_a) u = *(const bf16x8*)(a.p + n * a.sn + d * a.sd + h * a.sh + w * a.sw + grp * 8);
+    const int bd = d - od, bh = h - oh, bw = w - ow;
+    const bool in = (unsigned)bd < (unsigned)b.D && (unsigned)bh < (unsigned)b.H && (unsigned)bw < (unsigned)b.W;
+    if (in) v = *(const bf16x8*)(b.p + n * b.sn + bd * b.sd + bh * b.sh + bw * b.sw + grp * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = has_a ? (in ? (short)f2bf(bf2f((bf16_t)u[k]) + bf2f((bf16_t)v[k])) : u[k]) : v[k];
+    *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8) = o;
+  }
+}
+extern "C" int rg_add_pad(const rg_tensor* a, const rg_tensor* b, const rg_tensor* y, const int32_t offset[3], rg_stream s) {
+  CL5 A, B, Y; int rc;
+  if ((rc = rg_as_cl5(b, &B, "add_pad.b")) || (rc = rg_as_cl5(y, &Y, "add_pad.y"))) return rc;
+  const int has_a = a && a->ptr;
+  memset(&A, 0, sizeof(A));
+  if (has_a) {
+    if ((rc = rg_as_cl5(a, &A, "add_pad.a"))) return rc;
+    if (A.N != Y.N || A.C != Y.C || A.D != Y.D || A.H != Y.H || A.W != Y.W) RG_FAIL(RG_ERR_BAD_SHAPE, "add_pad: a / y shape mismatch");
+  }
+  if (B.N != Y.N || B.C != Y.C || offset[0] < 0 || offset[1] < 0 || offset[2] < 0 || offset[0] + B.D > Y.D || offset[1] + B.H > Y.H ||
+      offset[2] + B.W > Y.W) RG_FAIL(RG_ERR_BAD_SHAPE, "add_pad: b does not fit inside y at the given offset");
+  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
+  hipLaunchKernelGGL(add_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, A, B, Y, offset[0], offset[1], offset[2], has_a);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
 // ---------------------------------------------------------------------------- (kh,kw) taps <-> channels of a 1-channel volume
 // A C-channel conv whose other side has ONE channel (the generator's 7^3 stem and its composed 64->1 tail) re-reads the
 // C-channel tensor once per tap.  Folding the KH*KW in-plane taps of the one-channel side into channels leaves a KD-tap

@@ -851,8 +851,50 @@ class _DiagSum(torch.autograd.Function):
         return _DiagSpread.apply(g, kh, kw, -sign, h, w), None, None, None, None, None, gb
 
 
+class _Fork(torch.autograd.Function):
+    """x -> (x, x) for an activation with two consumers (the U-Net's skip connections): the two gradients are summed by the
+    rg_add kernel instead of torch's strided add on padded channels-last views (1.0 ms for 72 x 92^3 on MI355X, 20x slower)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        ga, gb = as_cl(ga), as_cl(gb)
+        y = cl_empty(*ga.shape, ga.device)
+        _lib.check(_lib.lib().rg_add(C.byref(desc(ga)), C.byref(desc(gb)), C.byref(desc(y)), _stream()), "rg_add")
+        return y
+
+
+def fork(x):
+    return _Fork.apply(x)
+
+
+class _CenterCrop(torch.autograd.Function):
+    """Zero-copy centre crop whose backward zero-pads with one rg_add_pad pass (torch: zeros + strided copy)."""
+
+    @staticmethod
+    def forward(ctx, x, shape):
+        off = [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)]
+        ctx.cfg = (tuple(x.shape), off)
+        return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, off = ctx.cfg
+        g = as_cl(g)
+        y = cl_empty(*shape, g.device)
+        _lib.check(_lib.lib().rg_add_pad(None, C.byref(desc(g)), C.byref(desc(y)), i3(off), _stream()), "rg_add_pad")
+        return y, None
+
+
 def center_crop(x, shape):
     """Zero-copy centre crop (networks/UNet.py:97-106,327-336)."""
+    if x.dim() == 5 and x.requires_grad and is_cl(x) and tuple(x.shape[-3:]) != tuple(shape):
+        return _CenterCrop.apply(x, tuple(int(v) for v in shape))
     off = [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)]
     return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
 

@@ -272,7 +272,11 @@ class UNet(nn.Module):
                 f_left = ops.enter(hipnn.passthrough(self.noise_layer, f_left))
             fs_out = [f_left] * self.num_heads
         else:
-            g_in = self.l_down[i](f_left)
+            if f_left.is_cuda and f_left.requires_grad and ops.is_cl(f_left):
+                f_left, f_down = ops.fork(f_left)  # two consumers: their gradients are summed by one HIP pass
+            else:
+                f_down = f_left
+            g_in = self.l_down[i](f_down)
             gs_out = self.rec_forward(level - 1, g_in)
             fs_out = []
             for h in range(self.num_heads):
