@@ -64,6 +64,8 @@ _SIGS = {
     "rg_pad3d_bwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
     "rg_add": (C.c_int, [_T, _T, _T, C.c_void_p]),
     "rg_diag_spread": (C.c_int, [_T, _T, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "rg_d2s_add_act": (C.c_int, [_T, _T, _T, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "rg_d2s_add_act_bwd": (C.c_int, [_T, _T, _T, _T, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "rg_add_pad": (C.c_int, [_T, _T, _T, C.c_void_p, C.c_void_p]),
     "rg_subpixel_weights": (C.c_int, [_T, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rg_subpixel_weights_bwd": (C.c_int, [C.c_void_p, C.c_void_p, _T, C.c_int, C.c_void_p]),

@@ -719,6 +719,77 @@ extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int k
   return RG_OK;
 }
 
+// ---------------------------------------------------------------------------- depth-to-space + add + activation (sub-pixel up-conv)
+// out[n, o, c] = act( y[n, o, c] + z[n, (o + off) >> 1, parity(o + off) * C + c] )      (per dimension; parity = pd*4 + ph*2 + pw)
+// z holds, on the low-resolution grid, the 8 parity classes of the upsampled operand's contribution (ops.upcat_conv3d).
+// Backward: g = gout * act'(out) goes to y unchanged and to z through the inverse shuffle (cells the crop cut off get 0).
+__global__ void d2s_add_act_kernel(CL5 y, CL5 z, CL5 out, int od, int oh, int ow, int act, float slope) {
+  const int G8 = out.lanes / 8;
+  const long total = (long)out.N * out.D * out.H * out.W * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int w = (int)(t % out.W); t /= out.W; const int h = (int)(t % out.H); t /= out.H; const int d = (int)(t % out.D); const int n = (int)(t / out.D);
+    const int qd = d + od, qh = h + oh, qw = w + ow;
+    const int par = ((qd & 1) << 2) | ((qh & 1) << 1) | (qw & 1);
+    const bf16x8 u = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
+    const bf16x8 v = *(const bf16x8*)(z.p + n * z.sn + (qd >> 1) * z.sd + (qh >> 1) * z.sh + (qw >> 1) * z.sw + (long)par * out.C + grp * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = grp * 8 + k < out.C ? (short)f2bf(act_fwd(bf2f((bf16_t)u[k]) + bf2f((bf16_t)v[k]), act, slope)) : (short)0;
+    *(bf16x8*)(out.p + n * out.sn + d * out.sd + h * out.sh + w * out.sw + grp * 8) = o;
+  }
+}
+// one thread per (low-res cell, parity, 8 channels): writes gz everywhere (zeros where the crop cut) and g where in range
+__global__ void d2s_add_act_bwd_kernel(CL5 gout, CL5 out, CL5 g, CL5 gz, int od, int oh, int ow, int act, float slope) {
+  const int C = g.C, G8 = C / 8;
+  const long total = (long)gz.N * gz.D * gz.H * gz.W * 8 * G8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int grp = (int)(i % G8); long t = i / G8;
+    const int par = (int)(t % 8); t /= 8;
+    const int jw = (int)(t % gz.W); t /= gz.W; const int jh = (int)(t % gz.H); t /= gz.H; const int jd = (int)(t % gz.D); const int n = (int)(t / gz.D);
+    const int d = 2 * jd + ((par >> 2) & 1) - od, h = 2 * jh + ((par >> 1) & 1) - oh, w = 2 * jw + (par & 1) - ow;
+    bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) {
+      const bf16x8 gv = *(const bf16x8*)(gout.p + n * gout.sn + d * gout.sd + h * gout.sh + w * gout.sw + grp * 8);
+      bf16x8 yv = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (act != RG_ACT_NONE) yv = *(const bf16x8*)(out.p + n * out.sn + d * out.sd + h * out.sh + w * out.sw + grp * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (short)f2bf(bf2f((bf16_t)gv[k]) * act_bwd_from_y(bf2f((bf16_t)yv[k]), act, slope));
+      *(bf16x8*)(g.p + n * g.sn + d * g.sd + h * g.sh + w * g.sw + grp * 8) = o;
+    }
+    *(bf16x8*)(gz.p + n * gz.sn + jd * gz.sd + jh * gz.sh + jw * gz.sw + (long)par * C + grp * 8) = o;
+  }
+}
+static int d2s_check(const CL5& Y, const CL5& Z, const int32_t off[3], const char* what) {
+  if (Y.C % 8 || Z.C != 8 * Y.C || Z.N != Y.N) { rg_set_error("%s: z must have 8 x the channels of y (a multiple of 8)", what); return RG_ERR_BAD_SHAPE; }
+  const int S[3] = {Y.D, Y.H, Y.W}, J[3] = {Z.D, Z.H, Z.W};
+  for (int k = 0; k < 3; ++k)
+    if (off[k] < 0 || off[k] > 1 || (S[k] - 1 + off[k]) / 2 >= J[k]) { rg_set_error("%s: output extent does not fit the low-resolution grid", what); return RG_ERR_BAD_SHAPE; }
+  return RG_OK;
+}
+extern "C" int rg_d2s_add_act(const rg_tensor* y, const rg_tensor* z, const rg_tensor* out, const int32_t offset[3], int act, float slope, rg_stream s) {
+  CL5 Y, Z, O; int rc;
+  if ((rc = rg_as_cl5(y, &Y, "d2s.y")) || (rc = rg_as_cl5(z, &Z, "d2s.z")) || (rc = rg_as_cl5(out, &O, "d2s.out")) || (rc = d2s_check(Y, Z, offset, "d2s_add_act"))) return rc;
+  if (O.N != Y.N || O.C != Y.C || O.D != Y.D || O.H != Y.H || O.W != Y.W) RG_FAIL(RG_ERR_BAD_SHAPE, "d2s_add_act: y / out shape mismatch");
+  const long total = (long)O.N * O.D * O.H * O.W * (O.lanes / 8);
+  hipLaunchKernelGGL(d2s_add_act_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Y, Z, O, offset[0], offset[1], offset[2], act, slope);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_d2s_add_act_bwd(const rg_tensor* gout, const rg_tensor* out, const rg_tensor* g, const rg_tensor* gz, const int32_t offset[3],
+                                  int act, float slope, rg_stream s) {
+  CL5 GO, O, G, GZ; int rc;
+  if ((rc = rg_as_cl5(gout, &GO, "d2s_bwd.gout")) || (rc = rg_as_cl5(g, &G, "d2s_bwd.g")) || (rc = rg_as_cl5(gz, &GZ, "d2s_bwd.gz")) ||
+      (rc = d2s_check(G, GZ, offset, "d2s_add_act_bwd"))) return rc;
+  memset(&O, 0, sizeof(O));
+  if (act != RG_ACT_NONE && (rc = rg_as_cl5(out, &O, "d2s_bwd.out"))) return rc;
+  if (GO.N != G.N || GO.C != G.C || GO.D != G.D || GO.H != G.H || GO.W != G.W) RG_FAIL(RG_ERR_BAD_SHAPE, "d2s_add_act_bwd: gout / g shape mismatch");
+  const long total = (long)GZ.N * GZ.D * GZ.H * GZ.W * G.C;
+  hipLaunchKernelGGL(d2s_add_act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, GO, O, G, GZ, offset[0], offset[1], offset[2], act, slope);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
 // ---------------------------------------------------------------------------- sub-pixel weights of conv(nearest_upsample_x2(.))
 // A 3^3 convolution applied to a nearest-x2 upsampled tensor is, per output parity p (one bit per dimension), a 2^3 convolution
 // on the low-resolution tensor: taps that fall on the same low-resolution cell s are summed —

@@ -39,6 +39,8 @@ def desc(t):
     for i in range(t.dim()):
         d.sizes[i] = t.shape[i]
         d.strides[i] = t.stride(i)
+    if t.dim() and t.shape[0] == 1:
+        d.strides[0] = 0  # a length-1 leading dimension is never stepped; views renormalise its stride to odd values
     return d
 
 
@@ -83,8 +85,8 @@ def is_cl(t):
     st = t.stride()
     if c > 1 and st[1] != 1:
         return False
-    if st[4] < lanes_of(c) or any(s % 8 for s in (st[0], st[2], st[3], st[4])):
-        return False
+    if st[4] < lanes_of(c) or any(s % 8 for s in (st[2], st[3], st[4])) or (n > 1 and st[0] % 8):
+        return False  # (the stride of a length-1 batch dimension is arbitrary: views renormalise it)
     return t.data_ptr() % 16 == 0
 
 
@@ -696,17 +698,34 @@ def upcat_conv3d(f, g, target, weight, bias, act="none", slope=0.0):
     jhi = [(t - 3 + ci) >> 1 for t, ci in zip(T, c)]
     wf, weff = _SubpixelWeights.apply(weight, cf)
     y = conv3d(center_crop(f, T), wf, bias)
-    gw = g[:, :, jlo[0]:jhi[0] + 2, jlo[1]:jhi[1] + 2, jlo[2]:jhi[2] + 2]
+    gw = crop(g, jlo, [b - a + 2 for a, b in zip(jlo, jhi)])
     z = conv3d(gw, weff, None)                                         # (N, 8*Cout, J, J, J), channels-last
-    n, _, jd, jh, jw = z.shape
-    zm = z.permute(0, 2, 3, 4, 1)
-    if not zm.is_contiguous():
-        zm = zm.contiguous()
-    u = zm.view(n, jd, jh, jw, 2, 2, 2, cout).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(n, 2 * jd, 2 * jh, 2 * jw, cout)
-    u = u.permute(0, 4, 1, 2, 3)                                       # logical (N, C, D, H, W), channel stride 1
-    o = [ci & 1 for ci in c]
-    u = u[:, :, o[0]:o[0] + T[0] - 2, o[1]:o[1] + T[1] - 2, o[2]:o[2] + T[2] - 2]
-    return activation(add(y, u), act, slope)
+    return _D2SAddAct.apply(y, z, tuple(ci & 1 for ci in c), act, float(slope))
+
+
+class _D2SAddAct(torch.autograd.Function):
+    """act(y + depth_to_space(z)[crop]) in one pass, and its backward in one pass (rg_d2s_add_act / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, y, z, off, act, slope):
+        y, z = as_cl(y), as_cl(z)
+        out = cl_empty(*y.shape, y.device)
+        _lib.check(_lib.lib().rg_d2s_add_act(C.byref(desc(y)), C.byref(desc(z)), C.byref(desc(out)), i3(off), ACT[act], slope, _stream()),
+                   "rg_d2s_add_act")
+        ctx.save_for_backward(out if act != "none" else None)
+        ctx.cfg = (off, act, slope, tuple(z.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (out,) = ctx.saved_tensors
+        off, act, slope, zs = ctx.cfg
+        gout = as_cl(gout)
+        g = cl_empty(*gout.shape, gout.device)
+        gz = cl_empty(*zs, gout.device)
+        _lib.check(_lib.lib().rg_d2s_add_act_bwd(C.byref(desc(gout)), C.byref(desc(out)) if out is not None else None, C.byref(desc(g)),
+                                                 C.byref(desc(gz)), i3(off), ACT[act], slope, _stream()), "rg_d2s_add_act_bwd")
+        return g, gz, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- instance norm
@@ -873,12 +892,12 @@ def fork(x):
     return _Fork.apply(x)
 
 
-class _CenterCrop(torch.autograd.Function):
-    """Zero-copy centre crop whose backward zero-pads with one rg_add_pad pass (torch: zeros + strided copy)."""
+class _Crop(torch.autograd.Function):
+    """Zero-copy spatial crop whose backward zero-pads with one rg_add_pad pass, channels-last (torch: NCDHW zeros + strided
+    copy, which the next kernel would have to convert back)."""
 
     @staticmethod
-    def forward(ctx, x, shape):
-        off = [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)]
+    def forward(ctx, x, off, shape):
         ctx.cfg = (tuple(x.shape), off)
         return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
 
@@ -888,15 +907,20 @@ class _CenterCrop(torch.autograd.Function):
         g = as_cl(g)
         y = cl_empty(*shape, g.device)
         _lib.check(_lib.lib().rg_add_pad(None, C.byref(desc(g)), C.byref(desc(y)), i3(off), _stream()), "rg_add_pad")
-        return y, None
+        return y, None, None
+
+
+def crop(x, off, shape):
+    """x[..., off : off + shape] per spatial dimension (zero-copy)."""
+    off, shape = tuple(int(v) for v in off), tuple(int(v) for v in shape)
+    if x.dim() == 5 and x.requires_grad and is_cl(x) and tuple(x.shape[-3:]) != shape:
+        return _Crop.apply(x, off, shape)
+    return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
 
 
 def center_crop(x, shape):
     """Zero-copy centre crop (networks/UNet.py:97-106,327-336)."""
-    if x.dim() == 5 and x.requires_grad and is_cl(x) and tuple(x.shape[-3:]) != tuple(shape):
-        return _CenterCrop.apply(x, tuple(int(v) for v in shape))
-    off = [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)]
-    return x[..., off[0]:off[0] + shape[0], off[1]:off[1] + shape[1], off[2]:off[2] + shape[2]]
+    return crop(x, [(a - b) // 2 for a, b in zip(x.shape[-3:], shape)], shape)
 
 
 # ---------------------------------------------------------------------------------------------- losses
