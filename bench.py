@@ -308,6 +308,9 @@ def cpu_baseline_aux(workload, size):
 
 def main():
     a = parse()
+    if os.environ.get("RAYGUN_AMD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RAYGUN_AMD_BENCH_WATCHDOG"]), exit=True)
     from raygun_amd import ops, parallel
     rank, local, world = parallel.init_from_env()
     if world != max(1, a.gpus) and rank == 0:
