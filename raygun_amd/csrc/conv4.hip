@@ -52,7 +52,7 @@ __device__ __forceinline__ void ld4_wait(bf16x8& f) { asm volatile("s_waitcnt lg
 // two pieces (k-half 0 and 1) up in an LDS table {byte offset of (tap, lane group), packed tap displacement}.
 struct PieceInfo { int off; int disp; };  // disp < 0: piece past the end of K
 template <int FM, int FN, bool CHECK, bool FLAT>
-__global__ __launch_bounds__(256, (FM >= 4 ? 2 : (FM == 1 ? 4 : 3))) void igemm4_kernel(Igemm4Args a) {
+__global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4_kernel(Igemm4Args a) {
   constexpr int BM = 64 * FM, BN = FN * 16;
   constexpr int BPIECES = ((BN / 8) + 3) / 4 * 4, BROWS = BPIECES * 8, BPW = BPIECES / 4;
   constexpr int BSTAGE = BROWS * 64;  // bf16 elements per weight stage
@@ -351,9 +351,16 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   const double e4 = b4 <= 512 ? b4 / 512.0 : b4 / (double)((b4 + 511) / 512 * 512);
   const char* e = getenv("RG_FM");
   int fm = e ? atoi(e) : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
+  // 192-row tiles (FM = 3, 144-channel tiles only) for grids that leave the last round of 256- and 128-row tiles half empty
+  // (2592 -> 2592 at 17^3: 360 / 468 / 702 tiles -> 821 TFLOP/s with FM = 2, 887 with FM = 3); never for grids below one tile per CU
+  if (!e && fn == 9) {
+    const long b3 = ((a.M + 191) / 192) * ntn;
+    const double e3 = b3 <= 512 ? b3 / 512.0 : b3 / (double)((b3 + 511) / 512 * 512);
+    if (b3 >= 256 && 950.0 * e3 > 1.03 * (fm == 4 ? 1030.0 * e4 : 880.0 * e2)) fm = 3;
+  }
   // small grids (PatchGAN's 15^3/16^3 layers, the parity classes of the transposed convs): 64-row tiles so that more CUs get a tile
   if (!e && fm == 2 && b2 < 192) fm = 1;
-#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st); \
+#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else if (fm == 3 && FN_ == 9) launch_igemm4<3, 9>(a, check, flat != 0, st); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st); \
                         else launch_igemm4<2, FN_>(a, check, flat != 0, st); } while (0)
   switch (fn) {
     case 1: RG_L4(1); break;
