@@ -322,7 +322,9 @@ def main():
     if a.workload in ("predict", "segment"):
         return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
-    step, info = (build_unet if a.workload == "unet" else build_cyclegan)(dev, size, seed=rank)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
+        step, info = (build_unet if a.workload == "unet" else build_cyclegan)(dev, size, seed=rank)
     sync = parallel.GradSync()
 
     def barrier():

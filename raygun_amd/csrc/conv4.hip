@@ -494,6 +494,152 @@ __global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
   }
 }
 
+// ---- thin kernel with kw reuse ---------------------------------------------------------------------------------------------
+// igemm_thin re-reads every input voxel once per tap: 27 x 32 B per 24-B output row of a 12 -> 12 channel 3^3 layer, and the
+// texture path (64 B/clk/CU) is what bounds it (55 % of that peak at 192^3).  Here a 16-row MFMA fragment is 16 consecutive
+// voxels of ONE W line (fragments are line-aligned; the tail of a line is masked), so the kw = 1, 2 taps of row r are the
+// kw = 0 voxels r+1, r+2 of the same line (r-1, r-2 when the taps run backwards): every wave parks the (kd, kh, 8-channel piece)
+// operands of a fragment plus its two neighbour voxels in a private LDS strip and reads the shifted taps from there — one third
+// of the global loads, no special cases.  Waves only read their own strips, in program order: no barrier.
+// K order: base piece bp = (kd*TH + kh)*cp + c8, four per MFMA group (one per 16-lane row), three MFMAs (kw) per group; the
+// weights stay in igemm_thin's LDS layout and are addressed by their piece index P = ((kd*TH + kh)*TW + kw)*cp + c8.
+template <int FM, bool CHECK>
+__global__ __launch_bounds__(256) void igemm_thin3_kernel(Igemm4Args a) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+  const int nk = a.krow >> 6;
+  bf16_t* wl = (bf16_t*)smem;                                  // [nk][16][64] swizzled
+  constexpr int SE = 20;                                       // strip entries per (piece row, fragment): 16 + 2, padded
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int BP = a.TD * a.TH * a.cp, NG = (BP + 3) >> 2;
+  int4* gtab = (int4*)(smem + (size_t)nk * 2048);              // [(NG+2)*4] base pieces: {byte offset, od | oh << 16, P0, valid}; the tail is invalid
+  unsigned char* strip = smem + (size_t)nk * 2048 + (size_t)(NG + 2) * 64 + (size_t)(wave * 4 + fg) * FM * SE * 16;
+  for (int q = tid; q < 16 * (a.krow >> 3); q += 256) {
+    const int row = q / (a.krow >> 3), kp = q - row * (a.krow >> 3);
+    const u32x4_t v = *(const u32x4_t*)(a.w + (long)row * a.krow + kp * 8);
+    *(u32x4_t*)(wl + (kp >> 3) * 1024 + row * 64 + (((kp & 7) ^ (row >> 1)) << 3)) = v;
+  }
+  for (int bp = tid; bp < (NG + 2) * 4; bp += 256) {
+    const int q = bp / a.cp, c8 = bp - q * a.cp;
+    const int kd = q / a.TH, kh = q - kd * a.TH;
+    const int od = kd * a.ts[0], oh = kh * a.ts[1];
+    const bool ok = bp < BP;
+    gtab[bp] = make_int4(ok ? ((int)(od * a.xsd + oh * a.xsh) + c8 * 8) * 2 : 0, ok ? ((od + 512) | ((oh + 512) << 16)) : (512 | (512 << 16)),
+                         ok ? q * a.TW * a.cp + c8 : 0, ok ? 1 : 0);
+  }
+  __syncthreads();
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.xbytes, 0x00020000);
+  const int dir = a.ts[2], shift0 = dir < 0 ? 2 : 0;
+  const int fpl = (a.RW + 15) >> 4;                            // fragments per W line
+  const long nfrag = (long)a.N * a.RD * a.RH * fpl;
+  const int ei = (fr >> 1) & (FM - 1), ee = fr & 1;            // this lane's edge duty: fragment ei, neighbour voxel ee (lanes fr < 2*FM)
+  const int eslot = (ei * SE + (fr < 2 * FM ? (dir > 0 ? 16 + ee : ee) : 18 + ee)) * 16;
+  float bias4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias4[r] = (a.bias && fg * 4 + r < a.cout) ? a.bias[fg * 4 + r] : 0.f;
+
+  for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const long f0 = ((long)tile * 4 + wave) * FM;
+    int rd0[FM], rh0[FM], rw0[FM]; unsigned rbase[FM]; int yoff[FM];
+    int ed0 = 0, eh0 = 0, ew0 = 0; unsigned ebase = IG4_OOB;
+    {
+      // one division chain for the wave's first fragment, the others step one fragment on with carries
+      unsigned t = (unsigned)f0;
+      int wf = (int)(t % (unsigned)fpl); t /= (unsigned)fpl;
+      int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+      int rd = (int)(t % (unsigned)a.RD); int n = (int)(t / (unsigned)a.RD);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const bool live = f0 + i < nfrag;
+        const int rw = wf * 16 + fr;
+        rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw + a.tb[2];
+        const long lbase = n * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh;
+        rbase[i] = live ? (unsigned)((lbase + rw0[i] * a.xsw) * 2) : IG4_OOB;   // rows beyond RW still feed their neighbours
+        yoff[i] = live && rw < a.RW ? (int)(n * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh + (long)(rw * a.os[2] + a.oo[2]) * a.ysw) : -1;
+        // neighbour voxels of fragment i (lanes 2i, 2i+1 of every piece row): 16, 17 past the fragment start (taps forward) or 2, 1 before it
+        const int w_e = wf * 16 + a.tb[2] + (dir > 0 ? 16 + ee : ee - 2);
+        const bool mine = i == ei;
+        ed0 = mine ? rd0[i] : ed0; eh0 = mine ? rh0[i] : eh0; ew0 = mine ? w_e : ew0;
+        ebase = mine ? (live ? (unsigned)((lbase + (long)w_e * a.xsw) * 2) : IG4_OOB) : ebase;
+        if (++wf == fpl) { wf = 0; if (++rh == a.RH) { rh = 0; if (++rd == a.RD) { rd = 0; ++n; } } }
+      }
+      if (fr >= 2 * FM) ebase = IG4_OOB;
+    }
+    f32x4 acc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4_t xb[2][FM], xe[2];
+    auto issue = [&](int g, u32x4_t (&b)[FM], u32x4_t& e) {  // always FM + 1 loads (groups past the end read out of range)
+      const int4 t = gtab[g * 4 + fg];
+      const int off = t.x, od = (t.y & 0xffff) - 512, oh = (t.y >> 16) - 512;
+      const bool ok = t.w != 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        bool k = ok;
+        k &= ((unsigned)rw0[i] < (unsigned)a.IW);  // rows past the line end may point past the input line
+        if (CHECK) k &= ((unsigned)(rd0[i] + od) < (unsigned)a.ID) & ((unsigned)(rh0[i] + oh) < (unsigned)a.IH);
+        b[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(k ? rbase[i] + (unsigned)off : IG4_OOB), 0, 0);
+      }
+      bool k = ok && ((unsigned)ew0 < (unsigned)a.IW);
+      if (CHECK) k &= ((unsigned)(ed0 + od) < (unsigned)a.ID) & ((unsigned)(eh0 + oh) < (unsigned)a.IH);
+      e = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(k ? ebase + (unsigned)off : IG4_OOB), 0, 0);
+    };
+    auto step = [&](int g, u32x4_t (&b)[FM], u32x4_t& e) {
+      const int4 t = gtab[g * 4 + fg];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) *(u32x4_t*)(strip + (i * SE + fr + shift0) * 16) = b[i];
+      *(u32x4_t*)(strip + eslot) = e;  // lanes without edge duty write zeros to a pad entry
+      __builtin_amdgcn_wave_barrier();
+      u32x4_t x1[FM], x2[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        x1[i] = *(const u32x4_t*)(strip + (i * SE + fr + shift0 + dir) * 16);
+        x2[i] = *(const u32x4_t*)(strip + (i * SE + fr + shift0 + 2 * dir) * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int P = t.z + (t.w ? kw * a.cp : 0);   // piece index of tap kw (pad lanes: piece 0, their operand is zero)
+        const bf16x8 wv = *(const bf16x8*)(wl + (P >> 3) * 1024 + fr * 64 + (((P & 7) ^ (fr >> 1)) << 3));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          bf16x8 f;
+          if (kw == 0) __builtin_memcpy(&f, &b[i], 16); else if (kw == 1) __builtin_memcpy(&f, &x1[i], 16); else __builtin_memcpy(&f, &x2[i], 16);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, f, acc[i], 0, 0, 0);
+        }
+      }
+    };
+    // Two statically indexed register sets, one K group of look-ahead.  Every iteration issues both its look-ahead groups
+    // unconditionally (groups past the end are invalid table entries: out-of-range loads, no memory traffic), so the loop body is
+    // straight-line as far as memory operations go and hipcc's vmcnt bookkeeping stays exact (with loads under `if (g + 1 < NG)`
+    // it merged the paths and waited for the YOUNGER set too).  At most two dummy groups per tile: the kernel is used for
+    // cp >= 4 (>= 9 groups per tile); 16-lane layers (5 groups) stay on igemm_thin.
+    issue(0, xb[0], xe[0]);
+    for (int g = 0; g < NG; g += 2) {
+      issue(g + 1, xb[1], xe[1]);
+      step(g, xb[0], xe[0]);
+      issue(g + 2, xb[0], xe[0]);
+      if (g + 1 < NG) step(g + 1, xb[1], xe[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      if (yoff[i] < 0) continue;
+      bf16_t* yrow = a.y + yoff[i];
+      const int c = fg * 4;
+      if (c >= a.cout_lanes) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (c + r < a.cout) v = act_fwd(acc[i][r] + bias4[r], a.act, a.slope);
+        o[r] = (short)f2bf(v);
+      }
+      *(bf16x4*)(yrow + c) = o;
+    }
+  }
+}
+
 // weights-resident thin kernel: Cout <= 16 and the packed matrix (plus the piece table) fits 128 KB of LDS
 bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p) {
   if (p->cout > 16) return false;
@@ -508,6 +654,23 @@ int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st) {
   // persistent workgroups: as many as fit the CUs (LDS-limited), every one stages the weights once
   int per_cu = (int)((160 * 1024) / (shm + 1024)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
   int grid = 256 * per_cu; if (grid > a.tiles_m) grid = a.tiles_m;
+  if (a.TW == 3 && (a.ts[2] == 1 || a.ts[2] == -1) && a.rs[2] == 1 && a.cp >= 4 && !getenv("RG_NO_THIN3")) {
+    const size_t shm3 = (size_t)a.krow * 32 + (size_t)((a.TD * a.TH * a.cp + 3) / 4 + 2) * 64 + (size_t)16 * FM * 20 * 16;
+    const long nfrag = (long)a.N * a.RD * a.RH * ((a.RW + 15) / 16);
+    a.tiles_m = (int)((nfrag + 4 * FM - 1) / (4 * FM));
+    int pc = (int)((160 * 1024) / (shm3 + 1024)); if (pc > 8) pc = 8; if (pc < 1) pc = 1;
+    int grid3 = 256 * pc; if (grid3 > a.tiles_m) grid3 = a.tiles_m;
+    rg_set_kernel_name("igemm_thin3_kernel<%d,%d>", FM, (int)check);
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      hipFuncSetAttribute((const void*)igemm_thin3_kernel<FM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      hipFuncSetAttribute((const void*)igemm_thin3_kernel<FM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      attr3_done = true;
+    }
+    if (check) hipLaunchKernelGGL((igemm_thin3_kernel<FM, true>), dim3(grid3), dim3(256), shm3, st, a);
+    else hipLaunchKernelGGL((igemm_thin3_kernel<FM, false>), dim3(grid3), dim3(256), shm3, st, a);
+    return RG_OK;
+  }
   rg_set_kernel_name("igemm_thin_kernel<%d,%d>", FM, (int)check);
   static bool attr_done = false;
   if (!attr_done) {
