@@ -313,3 +313,28 @@ def test_upcat_conv3d_equals_upsample_crop_concat_conv(gs, fs, target):
     close(got, ref, 3e-2)  # pre-activations of magnitude ~10 rounded to bf16 twice
     for a, r in zip(gg, rg):
         close(a, r, 2e-2)
+
+
+@pytest.mark.gpu
+def test_fork_and_crop_gradients():
+    """ops.fork / ops.crop (skip connections): forward are views, backward = one rg_add / rg_add_pad pass; against autograd on
+    plain slicing."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    x0 = torch.randn(2, 12, 9, 10, 11, device=dev).bfloat16().float()
+    xa = ops.to_cl(x0).requires_grad_()
+    a, b = ops.fork(xa)
+    c = ops.crop(b, (1, 2, 0), (6, 5, 9))
+    assert c.data_ptr() != 0 and tuple(c.shape) == (2, 12, 6, 5, 9) and torch.equal(c.float(), x0[:, :, 1:7, 2:7, 0:9])
+    ga = torch.randn(2, 12, 9, 10, 11, device=dev).bfloat16()
+    gc = torch.randn(2, 12, 6, 5, 9, device=dev).bfloat16()
+    (gx,) = torch.autograd.grad((a, c), xa, (ops.to_cl(ga), ops.to_cl(gc)))
+    ref = ga.float().clone()
+    ref[:, :, 1:7, 2:7, 0:9] += gc.float()
+    assert (gx.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()   # one bf16 rounding of the sum
+    # crop alone (its gradient is the zero-padded tensor, channels-last), centre_crop through the same op
+    xb = ops.to_cl(x0).requires_grad_()
+    (gz,) = torch.autograd.grad(ops.center_crop(xb, (5, 6, 7)), xb, ops.to_cl(torch.ones(2, 12, 5, 6, 7, device=dev)))
+    want = torch.zeros_like(x0); want[:, :, 2:7, 2:8, 2:9] = 1
+    assert ops.is_cl(gz) and torch.equal(gz.float(), want)
