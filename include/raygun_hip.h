@@ -160,7 +160,7 @@ int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign
  * reduce to on the low-resolution tensor, one per output parity; both channels-last ([out][kd][kh][kw][in]) fp32.  w: fp32
  * (O, C, 3,3,3), any strides.  _bwd: the adjoint — dw (strides as given) from the gradients of wf / weff (either may be NULL). */
 int rg_subpixel_weights(const rg_tensor* w, int cf, float* wf, float* weff, rg_stream s);
-/* out = act(y + depth_to_space(z)): z (N, 8*C, J, J, J) holds the 8 output parities of the upsampled operand's partial sums on the
+/* out = act(y + depth_to_space(z)) (y may be NULL: a plain shuffle): z (N, 8*C, J, J, J) holds the 8 output parities of the upsampled operand's partial sums on the
  * low-resolution grid (channel = parity*C + c); out[o] takes cell (o + offset) >> 1, parity (o + offset) & 1 per dimension
  * (offset in {0,1}).  _bwd: g = gout * act'(out) (the gradient of y) and gz = its inverse shuffle (0 where the crop cut). */
 int rg_d2s_add_act(const rg_tensor* y, const rg_tensor* z, const rg_tensor* out, const int32_t offset[3], int act, float slope, rg_stream s);

@@ -723,7 +723,7 @@ extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int k
 // out[n, o, c] = act( y[n, o, c] + z[n, (o + off) >> 1, parity(o + off) * C + c] )      (per dimension; parity = pd*4 + ph*2 + pw)
 // z holds, on the low-resolution grid, the 8 parity classes of the upsampled operand's contribution (ops.upcat_conv3d).
 // Backward: g = gout * act'(out) goes to y unchanged and to z through the inverse shuffle (cells the crop cut off get 0).
-__global__ void d2s_add_act_kernel(CL5 y, CL5 z, CL5 out, int od, int oh, int ow, int act, float slope) {
+__global__ void d2s_add_act_kernel(CL5 y, CL5 z, CL5 out, int od, int oh, int ow, int act, float slope, int has_y) {
   const int G8 = out.lanes / 8;
   const long total = (long)out.N * out.D * out.H * out.W * G8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -731,7 +731,8 @@ __global__ void d2s_add_act_kernel(CL5 y, CL5 z, CL5 out, int od, int oh, int ow
     const int w = (int)(t % out.W); t /= out.W; const int h = (int)(t % out.H); t /= out.H; const int d = (int)(t % out.D); const int n = (int)(t / out.D);
     const int qd = d + od, qh = h + oh, qw = w + ow;
     const int par = ((qd & 1) << 2) | ((qh & 1) << 1) | (qw & 1);
-    const bf16x8 u = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
+    bf16x8 u = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_y) u = *(const bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8);
     const bf16x8 v = *(const bf16x8*)(z.p + n * z.sn + (qd >> 1) * z.sd + (qh >> 1) * z.sh + (qw >> 1) * z.sw + (long)par * out.C + grp * 8);
     bf16x8 o;
 #pragma unroll
@@ -769,10 +770,15 @@ static int d2s_check(const CL5& Y, const CL5& Z, const int32_t off[3], const cha
 }
 extern "C" int rg_d2s_add_act(const rg_tensor* y, const rg_tensor* z, const rg_tensor* out, const int32_t offset[3], int act, float slope, rg_stream s) {
   CL5 Y, Z, O; int rc;
-  if ((rc = rg_as_cl5(y, &Y, "d2s.y")) || (rc = rg_as_cl5(z, &Z, "d2s.z")) || (rc = rg_as_cl5(out, &O, "d2s.out")) || (rc = d2s_check(Y, Z, offset, "d2s_add_act"))) return rc;
-  if (O.N != Y.N || O.C != Y.C || O.D != Y.D || O.H != Y.H || O.W != Y.W) RG_FAIL(RG_ERR_BAD_SHAPE, "d2s_add_act: y / out shape mismatch");
+  const int has_y = y && y->ptr;
+  if ((rc = rg_as_cl5(z, &Z, "d2s.z")) || (rc = rg_as_cl5(out, &O, "d2s.out")) || (rc = d2s_check(O, Z, offset, "d2s_add_act"))) return rc;
+  Y = O;
+  if (has_y) {
+    if ((rc = rg_as_cl5(y, &Y, "d2s.y"))) return rc;
+    if (O.N != Y.N || O.C != Y.C || O.D != Y.D || O.H != Y.H || O.W != Y.W) RG_FAIL(RG_ERR_BAD_SHAPE, "d2s_add_act: y / out shape mismatch");
+  }
   const long total = (long)O.N * O.D * O.H * O.W * (O.lanes / 8);
-  hipLaunchKernelGGL(d2s_add_act_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Y, Z, O, offset[0], offset[1], offset[2], act, slope);
+  hipLaunchKernelGGL(d2s_add_act_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Y, Z, O, offset[0], offset[1], offset[2], act, slope, has_y);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

@@ -340,9 +340,59 @@ def _parity_classes(size, stride, pad, K):
     return out
 
 
+_SUBPIX_T_IDX = None
+
+
+def _subpixel_weights_t(w):
+    """(Csrc, Cdst, 3,3,3) weight of a stride-2 / pad-1 transposed convolution -> the (8*Cdst, Csrc, 2,2,2) weight of the
+    ordinary convolution that computes all 8 output parities at once on the input grid: per dimension o = 2j + q reads
+    q = 0: tap 1 at x[j];  q = 1: tap 2 at x[j], tap 0 at x[j+1]  (_parity_classes); output channel = ((qd*2+qh)*2+qw)*Cdst + c.
+    Cached on the weight per version, like the packed operands."""
+    global _SUBPIX_T_IDX
+    cache = getattr(w, "_rg_pack_cache", None)
+    ver = (w._version, w.data_ptr())
+    if cache is not None and cache.get("ver") == ver and "subpix_t" in cache:
+        return cache["subpix_t"]
+    if _SUBPIX_T_IDX is None or _SUBPIX_T_IDX.device != w.device:
+        tap = {(0, 0): 1, (0, 1): None, (1, 0): 2, (1, 1): 0}
+        idx = []
+        for q in range(8):
+            for s_ in range(8):
+                ks = [tap[((q >> (2 - d)) & 1, (s_ >> (2 - d)) & 1)] for d in range(3)]
+                idx.append(27 if None in ks else (ks[0] * 3 + ks[1]) * 3 + ks[2])
+        _SUBPIX_T_IDX = torch.tensor(idx, dtype=torch.long, device=w.device)
+    csrc, cdst = w.shape[:2]
+    wt = w.detach().float().permute(1, 0, 2, 3, 4).reshape(cdst, csrc, 27)
+    wt = torch.cat([wt, wt.new_zeros(cdst, csrc, 1)], 2)
+    weff = wt[:, :, _SUBPIX_T_IDX].view(cdst, csrc, 8, 8).permute(2, 0, 1, 3).reshape(8 * cdst, csrc, 2, 2, 2).contiguous()
+    if cache is None or cache.get("ver") != ver:
+        cache = {"ver": ver}
+        try:
+            w._rg_pack_cache = cache
+        except Exception:
+            pass
+    cache["subpix_t"] = weff
+    return weff
+
+
 def _scatter_conv(src, w, bias, out, stride, pad, K, swap, act, slope):
     """out[o] = act(bias + sum_{i,k: o = i*s - p + k} src[i] . W[..k])  as one igemm launch per parity class."""
     size = out.shape[2:]
+    if (swap and tuple(stride) == (2, 2, 2) and tuple(K) == (3, 3, 3) and tuple(pad) == (1, 1, 1) and out.shape[1] % 8 == 0
+            and src.shape[1] >= 192 and all(o == 2 * i for o, i in zip(size, src.shape[2:]))
+            and os.environ.get("RAYGUN_AMD_SUBPIXEL_T", "1") != "0"):
+        # wide inputs: the 8 parity classes as ONE convolution with 8*Cout channels and 2^3 taps on the input grid (64/27 of
+        # the FLOPs, in one launch that fills the chip instead of eight 16-tile launches with 1..8-tap K loops: 256 -> 128 at
+        # 32^3 takes 0.18 ms instead of 0.64), then a depth-to-space shuffle
+        weff = _subpixel_weights_t(w)
+        n, _, D, H, W = src.shape
+        z = cl_empty(n, 8 * out.shape[1], D, H, W, src.device)
+        p = _conv_params(R=(D, H, W), T=(2, 2, 2), rstride=(1, 1, 1), tbase=(0, 0, 0), tstep=(1, 1, 1), ostride=(1, 1, 1),
+                         ooffset=(0, 0, 0), cout=8 * out.shape[1], act=act, slope=slope)
+        _igemm(src, pack_weights(weff, swap=0), bias.repeat(8) if bias is not None else None, z, p)
+        _lib.check(_lib.lib().rg_d2s_add_act(None, C.byref(desc(z)), C.byref(desc(out)), i3((0, 0, 0)), ACT["none"], 0.0, _stream()),
+                   "rg_d2s_add_act")
+        return
     classes = [_parity_classes(size[i], stride[i], pad[i], K[i]) for i in range(3)]
     if any(c["ntap"] == 0 for cl in classes for c in cl):
         out.zero_()  # some parity class has no tap (kernel smaller than stride): bias/act of zero handled below

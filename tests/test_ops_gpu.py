@@ -338,3 +338,30 @@ def test_fork_and_crop_gradients():
     (gz,) = torch.autograd.grad(ops.center_crop(xb, (5, 6, 7)), xb, ops.to_cl(torch.ones(2, 12, 5, 6, 7, device=dev)))
     want = torch.zeros_like(x0); want[:, :, 2:7, 2:8, 2:9] = 1
     assert ops.is_cl(gz) and torch.equal(gz.float(), want)
+
+
+@pytest.mark.gpu
+def test_wide_transposed_conv_subpixel_path():
+    """Stride-2 / k3 / pad-1 transposed convolutions with >= 192 input channels run as one 8*Cout-channel convolution +
+    depth-to-space (ops._scatter_conv fast path): ConvTranspose3d forward and the input gradient of a strided Conv3d, against torch."""
+    import torch.nn.functional as F
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    x = torch.randn(1, 192, 5, 6, 7, device=dev).bfloat16().float().requires_grad_()
+    w = (torch.randn(192, 24, 3, 3, 3, device=dev) * 0.05).bfloat16().float().requires_grad_()
+    b = torch.randn(24, device=dev)
+    ref = torch.tanh(F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1))
+    got = ops.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1, act="tanh")
+    assert tuple(got.shape) == (1, 24, 10, 12, 14)
+    assert (got.float() - ref).abs().max().item() <= 2e-2
+    go = torch.randn_like(ref).bfloat16().float()
+    for a, r in zip(torch.autograd.grad(got, (x, w), go), torch.autograd.grad(ref, (x, w), go)):
+        assert (a.float() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6
+    # strided conv: its backward-data is the same scatter with 192 source channels
+    xs = torch.randn(1, 16, 10, 12, 8, device=dev).bfloat16().float().requires_grad_()
+    ws = (torch.randn(192, 16, 3, 3, 3, device=dev) * 0.05).bfloat16().float()
+    gs = torch.randn(1, 192, 5, 6, 4, device=dev).bfloat16().float()
+    (rg,) = torch.autograd.grad(F.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
+    (gg,) = torch.autograd.grad(ops.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
+    assert (gg.float() - rg).abs().max().item() <= 2e-2 * rg.abs().max().item()
