@@ -353,14 +353,14 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   int fm = e ? atoi(e) : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
   // 192-row tiles (FM = 3, 144-channel tiles only) for grids that leave the last round of 256- and 128-row tiles half empty
   // (2592 -> 2592 at 17^3: 360 / 468 / 702 tiles -> 821 TFLOP/s with FM = 2, 887 with FM = 3); never for grids below one tile per CU
-  if (!e && fn == 9) {
+  if (!e && (fn == 9 || fn == 8) && a.rs[0] == 1 && a.rs[1] == 1 && a.rs[2] == 1) {  // (strided gathers measured slower with 192 rows)
     const long b3 = ((a.M + 191) / 192) * ntn;
     const double e3 = b3 <= 512 ? b3 / 512.0 : b3 / (double)((b3 + 511) / 512 * 512);
     if (b3 >= 256 && 950.0 * e3 > 1.03 * (fm == 4 ? 1030.0 * e4 : 880.0 * e2)) fm = 3;
   }
   // small grids (PatchGAN's 15^3/16^3 layers, the parity classes of the transposed convs): 64-row tiles so that more CUs get a tile
   if (!e && fm == 2 && b2 < 192) fm = 1;
-#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else if (fm == 3 && FN_ == 9) launch_igemm4<3, 9>(a, check, flat != 0, st); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st); \
+#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else if (fm == 3 && (FN_ == 9 || FN_ == 8)) launch_igemm4<3, (FN_ == 8 ? 8 : 9)>(a, check, flat != 0, st); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st); \
                         else launch_igemm4<2, FN_>(a, check, flat != 0, st); } while (0)
   switch (fn) {
     case 1: RG_L4(1); break;
