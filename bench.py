@@ -112,7 +112,7 @@ def build_cyclegan(dev, size, seed):
                       params=71848196)
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, tag="unet"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summaries (profiles/*_pmc_{fetch,write}_size.csv,
     separate --pmc passes).  FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950
     tallies 128-byte read requests at 64 B).  None when no profile names this kernel."""
@@ -122,7 +122,7 @@ def pmc_traffic(kernel_name):
     args = kernel_name[len(key):].strip("<>").split(",") if "<" in kernel_name else []
     out = {}
     for kind, scale in (("fetch", 2.0 * 1024), ("write", 1024.0)):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kind}_size.csv")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{tag}*_pmc_{kind}_size.csv")))
         if not files:
             return None
         best = None
@@ -249,7 +249,9 @@ def main_aux(a, rank, local, world, dev):
         avg = d["ms"] / max(1, d["launches"])
         ach = units * MWS_BYTES_PER_VOXEL / (avg * 1e-3) / 1e9
         roofline = dict(bound="hbm", kernel="mws_rounds_kernel", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, launches_per_step=1, avg_launch_ms=round(avg, 4),
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc_traffic("mws_rounds_kernel", "segment") if a.affs == "blobs" and size == 256 else None,
+                        traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_segment256_pmc_*.csv passes",
+                        launches_per_step=1, avg_launch_ms=round(avg, 4),
                         note="algorithmic bytes = 88 B/voxel (20 fp32 channels + u64 label); the pass is a dependency-ordered "
                              "union-find over sorted edges, bound by round latency and device-scope atomics, not by HBM streaming")
         res = dict(metric="Mvoxels/sec mutex watershed (prepare + 20 offsets, sep 3, strides 10)", unit="Mvoxels/s", dtype="f32 keys / i32 union-find",
