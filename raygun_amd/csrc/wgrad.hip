@@ -932,7 +932,9 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
     const long units = kg.units;
     const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
     const long target = kind == 3 ? 768 : 1536;  // workgroups aimed at (measured per tile shape)
-    long ns = (target + tl - 1) / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
+    // the targets are whole rounds of co-resident workgroups: round the split count DOWN so that the grid never spills a few
+    // workgroups into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815)
+    long ns = target / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
     const long ups = (units + ns - 1) / ns;
     *nsplit = (int)((units + ups - 1) / ups);
     *rows_per_split = ups;
