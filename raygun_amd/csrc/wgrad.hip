@@ -950,7 +950,7 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
     *rows_per_split = ups;  // units per split
     return;
   }
-  long want = (2048 + tiles - 1) / tiles;           // aim at >= 2048 workgroups
+  long want = 2048 / tiles;                         // aim at one round of 2048 co-resident workgroups, never a few more (rounded down)
   long maxs = (M + 64 * 8 - 1) / (64 * 8);           // at least 8 K-steps per split
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
