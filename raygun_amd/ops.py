@@ -746,7 +746,21 @@ def upcat_conv3d(f, g, target, weight, bias, act="none", slope=0.0):
     c = [(2 * a - t) // 2 for a, t in zip(g.shape[2:], T)]            # crop offset of the upsampled tensor
     jlo = [ci >> 1 for ci in c]
     jhi = [(t - 3 + ci) >> 1 for t, ci in zip(T, c)]
-    wf, weff = _SubpixelWeights.apply(weight, cf)
+    if torch.is_grad_enabled() and weight.requires_grad:
+        wf, weff = _SubpixelWeights.apply(weight, cf)
+    else:  # inference (the block runner): split once per weight version; the packed operands are cached on the two tensors
+        cache = getattr(weight, "_rg_pack_cache", None)
+        ver = (weight._version, weight.data_ptr())
+        if cache is None or cache.get("ver") != ver:
+            cache = {"ver": ver}
+            try:
+                weight._rg_pack_cache = cache
+            except Exception:
+                pass
+        if ("subpix_up", cf) not in cache:
+            with torch.no_grad():
+                cache[("subpix_up", cf)] = _SubpixelWeights.apply(weight.detach(), cf)
+        wf, weff = cache[("subpix_up", cf)]
     y = conv3d(center_crop(f, T), wf, bias)
     gw = crop(g, jlo, [b - a + 2 for a, b in zip(jlo, jhi)])
     z = conv3d(gw, weff, None)                                         # (N, 8*Cout, J, J, J), channels-last
