@@ -1,7 +1,7 @@
 """Timing of rg_mws_segment vs the C oracle (scratch).  usage: python scratch/bench_seg.py [size ...]"""
 import sys, time
 import numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import mws as O
 from raygun_amd import segment as S, synth
 

@@ -1,7 +1,7 @@
 """CPU simulation of the round-based mutex watershed rules (scratch): checks the early-execution rules against the oracle."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import mws as O
 from raygun_amd import synth
 

@@ -1,7 +1,7 @@
 """Randomised bit-exactness stress of rg_mws_segment against the C oracle (scratch; GPU box)."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import mws as O
 from raygun_amd.segment import compute_mws_segmentation
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
