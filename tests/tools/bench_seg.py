@@ -26,7 +26,7 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
         seg = S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mt)
         torch.cuda.synchronize(); tg = time.perf_counter() - t0
         line = f"n={n} {kind}: gpu {tg*1e3:.1f} ms = {n**3/tg/1e6:.2f} Mvox/s ({n**3*88/tg/1e9:.2f} GB/s) segments={int(seg.max())} masked={1-m.mean():.2f}"
-        if n <= 160:
+        if n <= int(os.environ.get("RG_ORACLE_MAX", "160")):
             t0 = time.perf_counter(); ref = O.compute_mws_segmentation(w, nb, 3, (10, 10, 10), m); tc = time.perf_counter() - t0
             line += f" | cpu {tc*1e3:.0f} ms = {n**3/tc/1e6:.2f} Mvox/s equal={bool((ref == seg).all())}"
         print(line, flush=True)
