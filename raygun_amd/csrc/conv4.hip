@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias4[r] = (a.bias && fg * 4 + r < a.cout) ? a.bias[fg * 4 + r] : 0.f;
 
+  const int xsn = (int)a.xsn, xsd = (int)a.xsd, xsh = (int)a.xsh, xsw = (int)a.xsw, ysn = (int)a.ysn, ysd = (int)a.ysd, ysh = (int)a.ysh, ysw = (int)a.ysw;
   for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
     const long mw = (long)tile * (64 * FM) + wave * (16 * FM);
     // row decode: one 32-bit division chain for fragment 0 (host guarantees M < 2^31), the other fragments step 16 rows
@@ -430,8 +431,9 @@ __global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
       for (int i = 0; i < FM; ++i) {
         const bool v = mw + i * 16 + fr < a.M;
         rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
-        rbase[i] = v ? (unsigned)((n * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw) * 2) : IG4_OOB;
-        yoff[i] = v ? (int)(n * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh + (long)(rw * a.os[2] + a.oo[2]) * a.ysw) : -1;
+        // 32-bit offsets: the launcher admits only tensors whose extents fit (M, x and y extents < 2^31)
+        rbase[i] = v ? (unsigned)(n * xsn + rd0[i] * xsd + rh0[i] * xsh + rw0[i] * xsw) * 2u : IG4_OOB;
+        yoff[i] = v ? n * ysn + (rd * a.os[0] + a.oo[0]) * ysd + (rh * a.os[1] + a.oo[1]) * ysh + (rw * a.os[2] + a.oo[2]) * ysw : -1;
         rw += 16;
         while (rw >= a.RW) { rw -= a.RW; if (++rh == a.RH) { rh = 0; if (++rd == a.RD) { rd = 0; ++n; } } }
       }
@@ -539,6 +541,7 @@ __global__ __launch_bounds__(256) void igemm_thin3_kernel(Igemm4Args a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias4[r] = (a.bias && fg * 4 + r < a.cout) ? a.bias[fg * 4 + r] : 0.f;
 
+  const int xsn = (int)a.xsn, xsd = (int)a.xsd, xsh = (int)a.xsh, xsw = (int)a.xsw, ysn = (int)a.ysn, ysd = (int)a.ysd, ysh = (int)a.ysh, ysw = (int)a.ysw;
   for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
     const long f0 = ((long)tile * 4 + wave) * FM;
     int rd0[FM], rh0[FM], rw0[FM]; unsigned rbase[FM]; int yoff[FM];
@@ -554,14 +557,14 @@ __global__ __launch_bounds__(256) void igemm_thin3_kernel(Igemm4Args a) {
         const bool live = f0 + i < nfrag;
         const int rw = wf * 16 + fr;
         rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw + a.tb[2];
-        const long lbase = n * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh;
-        rbase[i] = live ? (unsigned)((lbase + rw0[i] * a.xsw) * 2) : IG4_OOB;   // rows beyond RW still feed their neighbours
-        yoff[i] = live && rw < a.RW ? (int)(n * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh + (long)(rw * a.os[2] + a.oo[2]) * a.ysw) : -1;
+        const int lbase = n * xsn + rd0[i] * xsd + rh0[i] * xsh;   // 32-bit: extents < 2^31 (launcher)
+        rbase[i] = live ? (unsigned)(lbase + rw0[i] * xsw) * 2u : IG4_OOB;   // rows beyond RW still feed their neighbours
+        yoff[i] = live && rw < a.RW ? n * ysn + (rd * a.os[0] + a.oo[0]) * ysd + (rh * a.os[1] + a.oo[1]) * ysh + (rw * a.os[2] + a.oo[2]) * ysw : -1;
         // neighbour voxels of fragment i (lanes 2i, 2i+1 of every piece row): 16, 17 past the fragment start (taps forward) or 2, 1 before it
         const int w_e = wf * 16 + a.tb[2] + (dir > 0 ? 16 + ee : ee - 2);
         const bool mine = i == ei;
         ed0 = mine ? rd0[i] : ed0; eh0 = mine ? rh0[i] : eh0; ew0 = mine ? w_e : ew0;
-        ebase = mine ? (live ? (unsigned)((lbase + (long)w_e * a.xsw) * 2) : IG4_OOB) : ebase;
+        ebase = mine ? (live ? (unsigned)(lbase + w_e * xsw) * 2u : IG4_OOB) : ebase;
         if (++wf == fpl) { wf = 0; if (++rh == a.RH) { rh = 0; if (++rd == a.RD) { rd = 0; ++n; } } }
       }
       if (fr >= 2 * FM) ebase = IG4_OOB;
