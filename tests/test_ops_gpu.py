@@ -365,3 +365,25 @@ def test_wide_transposed_conv_subpixel_path():
     (rg,) = torch.autograd.grad(F.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
     (gg,) = torch.autograd.grad(ops.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
     assert (gg.float() - rg).abs().max().item() <= 2e-2 * rg.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout", [144, 128])
+def test_igemm4_192_row_tiles(cout, monkeypatch):
+    """The 192-row tile (FM = 3) of igemm4 is only picked for large grids; force it (RG_FM=3) on a small problem: forward and
+    backward-data against torch."""
+    import torch.nn.functional as F
+    from raygun_amd import ops
+    monkeypatch.setenv("RG_FM", "3")
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    x = torch.randn(1, 64, 9, 10, 11, device=dev).bfloat16().float().requires_grad_()
+    w = (torch.randn(cout, 64, 3, 3, 3, device=dev) * 0.05).bfloat16().float()
+    b = torch.randn(cout, device=dev)
+    ref = F.conv3d(x, w, b)
+    got = ops.conv3d(x, w, b)
+    assert (got.float() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    go = torch.randn_like(ref).bfloat16().float()
+    (rg,) = torch.autograd.grad(ref, x, go)
+    (gg,) = torch.autograd.grad(got, x, go)
+    assert (gg.float() - rg).abs().max().item() <= 1.5e-2 * rg.abs().max().item()
