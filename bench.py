@@ -5,7 +5,9 @@ Default workload = BASELINE.json's primary metric: 3-D U-Net (MTLSDModel, config
 valid, 259 146 829 parameters, num_affs 3) affinity train step on a synthetic 196^3 volume per GPU:
 forward + WeightedMSELoss_MTLSD + backward + Adam (+ RCCL gradient all-reduce for N > 1), bf16 storage /
 fp32 accumulate.  value = input Mvoxels/s over the whole job (196^3 * N / step time), "scaling": "weak".
-`--workload cyclegan` times the 3-D CycleGAN link train step at 128^3 (BASELINE's second figure, ms/step).
+The same run then times the 3-D CycleGAN link train step at 128^3 (BASELINE's second figure, ms/step) and reports it under
+`secondary` in the same line (`--no-secondary` skips it; `--workload cyclegan` times only that).  With --gpus N > 1 and no
+launcher (no RANK in the environment) bench.py starts its own N rank processes (RCCL).
 `--workload predict` times block-wise volume prediction (first half: 196^3 -> 104^3 blocks of the
 U-Net with 20 affinity channels over a synthetic uint8 volume resident in HBM); `--workload segment` times the mutex
 watershed (second half: segment.py's prepare + 20-offset / sep 3 / stride 10 mutex watershed of a synthetic structured
@@ -40,6 +42,7 @@ def parse():
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="unet workload: do not also time the CycleGAN 128^3 step")
     ap.add_argument("--cpu-size", type=int, default=0)
     return ap.parse_args()
 
@@ -205,7 +208,8 @@ def main_aux(a, rank, local, world, dev):
         units = nblk * 104 ** 3
 
         def step():
-            return P.predict_volume(model, vol, input_shape=[196] * 3, output_shape=[104] * 3, out_dtypes=[np.uint8, np.uint8])
+            # rank=0, world=1: every rank predicts ITS OWN whole volume (weak scaling), nothing is sharded a second time
+            return P.predict_volume(model, vol, input_shape=[196] * 3, output_shape=[104] * 3, out_dtypes=[np.uint8, np.uint8], rank=0, world=1)
     else:
         size = a.size or 256
         affs = structured_affs(size, rank, dev)
@@ -267,7 +271,7 @@ def main_aux(a, rank, local, world, dev):
                         avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
         res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks", unit="Mvoxels/s", dtype="bf16",
                    config=dict(workload=f"predict {size}^3 uint8 volume per GPU in {nblk} blocks, MTLSDModel(UNet ngf12 x6 3-level valid, "
-                                        "20 affinities + 10 LSDs), uint8 destinations in HBM", parallelism=f"blocks sharded x{world}"),
+                                        "20 affinities + 10 LSDs), uint8 destinations in HBM", parallelism=f"one volume of {nblk} blocks per GPU x{world}"),
                    blocks_per_s=round(nblk * world / (dt / a.steps), 2))
     res.update(value=round(units * world / (dt / a.steps) / 1e6, 3), n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic", roofline=roofline)
@@ -308,12 +312,94 @@ def cpu_baseline_aux(workload, size):
                 sample=f"forward of the CPU restatement on 2 blocks of 196^3 (torch {torch.__version__} fp32, oneDNN), {dt:.1f} s per block")
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (torchrun-style environment, rendezvous on
+    127.0.0.1, backend nccl = RCCL) from this parent, which has not touched the GPU.  Rank 0's stdout (the JSON line) is ours;
+    the other ranks' stdout goes to stderr.  Exit code: first non-zero child code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
+
+
+def run_train(a, workload, size, steps, warmup, rank, world, dev):
+    """Time `steps` train steps of `workload` ('unet' | 'cyclegan') after `warmup` untimed ones: barrier + synchronize on both
+    sides, MAX over ranks.  Returns the result dict (rank 0) or None."""
+    import contextlib
+    from raygun_amd import ops, parallel
+    with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
+        step, info = (build_unet if workload == "unet" else build_cyclegan)(dev, size, seed=rank)
+    sync = parallel.GradSync()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(sync)
+    barrier()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    sync.detach()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    ms = dt / steps * 1e3
+    kernels = {k: dict(launches=v["launches"] // steps, ms_per_step=v["ms"] / steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0)
+               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(dom[0]) if workload == "unet" else None,
+                        traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_pmc_*.csv passes of this workload",
+                        launches_per_step=dom[1]["launches"] // steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
+    flop = (UNET_FLOP_PER_STEP if workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if workload == "unet" else 128)) ** 3
+    executed = sum(v["flops"] for v in prof.values()) / steps  # what the conv / weight-gradient launches actually multiplied
+    res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if workload == "unet" else "CycleGAN 128^3 train-step ms",
+               value=round(size ** 3 * world / (dt / steps) / 1e6, 3) if workload == "unet" else round(ms, 3),
+               unit="Mvoxels/s" if workload == "unet" else "ms/step", n_gpus=world, steps=steps, warmup=warmup,
+               ms_per_step=round(ms, 3), higher_is_better=workload == "unet", scaling="weak", vs_baseline=None, dtype="bf16",
+               data="synthetic",
+               config=dict(workload=f"{workload} {size}^3 batch 1 per GPU, {info['model']}", params=info["params"],
+                           parallelism=f"dp{world}", precision="bf16 storage, fp32 accumulate, fp32 master weights + Adam state"),
+               # algorithmic = the reference network's FLOPs (SURVEY 8a) / step time; executed = the FLOPs of the launches the
+               # graph rewrites (DESIGN 3a, 3b) leave, summed over the step's conv + weight-gradient kernels / step time
+               algorithmic_tflop_per_step=round(flop / 1e12, 3), executed_tflop_per_step=round(executed / 1e12, 3),
+               step_tflops=round(flop / (dt / steps) / 1e12, 2), executed_tflops=round(executed / (dt / steps) / 1e12, 2),
+               step_frac_of_mfma_peak=round(flop / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+               executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+               roofline=roofline, kernels=kernels)
+    return res
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:  # no launcher: be one (before anything touches the GPU)
+        sys.exit(launch_ranks(a))
     if os.environ.get("RAYGUN_AMD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RAYGUN_AMD_BENCH_WATCHDOG"]), exit=True)
-    from raygun_amd import ops, parallel
+    from raygun_amd import parallel
     rank, local, world = parallel.init_from_env()
     if world != max(1, a.gpus) and rank == 0:
         print(f"[bench] warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -324,55 +410,26 @@ def main():
     if a.workload in ("predict", "segment"):
         return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
-        step, info = (build_unet if a.workload == "unet" else build_cyclegan)(dev, size, seed=rank)
-    sync = parallel.GradSync()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step(sync)
-    barrier()
-    ops.profile_start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(sync)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_stop()
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev)
+    if a.workload == "unet" and not a.no_secondary:
+        # BASELINE's metric string has a second half — "CycleGAN 128^3 train-step ms" (config 2; with N > 1: config 4): timed in
+        # the same run, after the U-Net's memory is released, and reported inside the same JSON line
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        sec = run_train(a, "cyclegan", 128, max(3, a.steps // 2), 2, rank, world, dev)
+        if res is not None and sec is not None:
+            res["secondary"] = dict(metric=sec["metric"], value=sec["value"], unit=sec["unit"], ms_per_step=sec["ms_per_step"],
+                                    steps=sec["steps"], warmup=sec["warmup"], higher_is_better=False, config=sec["config"],
+                                    algorithmic_tflop_per_step=sec["algorithmic_tflop_per_step"], executed_tflop_per_step=sec["executed_tflop_per_step"],
+                                    algorithmic_tflops=sec["step_tflops"], executed_tflops=sec["executed_tflops"],
+                                    executed_frac_of_mfma_peak=sec["executed_frac_of_mfma_peak"],
+                                    roofline={k: sec["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms")}
+                                    if sec["roofline"] else None,
+                                    kernel_launches_per_step=sum(k["launches"] for k in sec["kernels"].values()))
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
-    ms = dt / a.steps * 1e3
-    kernels = {k: dict(launches=v["launches"] // a.steps, ms_per_step=v["ms"] / a.steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0)
-               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
-    roofline = None
-    if dom:
-        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(dom[0]) if a.workload == "unet" else None,
-                        traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_pmc_*.csv passes of this workload",
-                        launches_per_step=dom[1]["launches"] // a.steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
-    flop = (UNET_FLOP_PER_STEP if a.workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if a.workload == "unet" else 128)) ** 3
-    res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if a.workload == "unet" else "CycleGAN 128^3 train-step ms",
-               value=round(size ** 3 * world / (dt / a.steps) / 1e6, 3) if a.workload == "unet" else round(ms, 3),
-               unit="Mvoxels/s" if a.workload == "unet" else "ms/step", n_gpus=world, steps=a.steps, warmup=a.warmup,
-               ms_per_step=round(ms, 3), higher_is_better=a.workload == "unet", scaling="weak", vs_baseline=None, dtype="bf16",
-               data="synthetic",
-               config=dict(workload=f"{a.workload} {size}^3 batch 1 per GPU, {info['model']}", params=info["params"],
-                           parallelism=f"dp{world}", precision="bf16 storage, fp32 accumulate, fp32 master weights + Adam state"),
-               step_tflops=round(flop / (dt / a.steps) / 1e12 * 1.0, 2), step_frac_of_mfma_peak=round(flop / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-               roofline=roofline, kernels=kernels)
     if world == 1 and not a.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_size or (196 if a.workload == "unet" else 48))

@@ -186,12 +186,20 @@ int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, float grad_scale, void* packed, const rg_pack_params* pp, rg_stream s);
 
-/* ---- mutex watershed (affogato.segmentation.compute_mws_segmentation, called at segment.py:197-199) */
+/* ---- mutex watershed (affogato.segmentation.compute_mws_segmentation, called at segment.py:197-199).
+ * affogato's Python wrapper (not vendored; signature as published: compute_mws_segmentation(weights, offsets,
+ * number_of_attractive_channels, strides=None, randomize_strides=False, invert_repulsive_weights=True, bias_cut=0., mask=None,
+ * algorithm='kruskal')) transforms the weights before sorting, in float32:  w[n_attractive:] = w[n_attractive:] * -1 + 1  when
+ * invert_repulsive_weights, then  w[:n_attractive] += bias_cut.  Both are applied here while the sort keys are formed (same
+ * float32 roundings), the caller's array is not modified.  The reference passes neither argument, so it gets invert = 1, bias 0. */
 typedef struct {
   int32_t shape[3];
   int32_t n_offsets, n_attractive;
   int32_t strides[3];     /* sub-sampling stride of repulsive edges */
   int32_t randomize_strides; /* must be 0 */
+  int32_t invert_repulsive_weights; /* affogato default: 1 */
+  float bias_cut;                   /* affogato default: 0 */
+  int32_t origin[3];      /* global coordinate of voxel (0,0,0): the stride grid is (coordinate + origin) % stride == 0 (slabs of a larger volume) */
 } rg_mws_params;
 int64_t rg_mws_workspace_bytes(const rg_mws_params* p);
 /* affs: float32 (n_offsets,Z,Y,X) already in "edge weight" form (segment.py:191-194); offsets int32 (n_offsets,3);

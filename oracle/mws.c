@@ -14,7 +14,10 @@
  *   - attractive edge: merge the two clusters unless a mutex constraint separates them;
  *     repulsive edge: add a mutex constraint between the two clusters if they differ;
  *   - labels: 1 + rank of the cluster's first voxel in raster order; masked-out voxels get 0.
- * Weights are taken as given (segment.py:191-194 prepares them); `affs` is (n_offsets, Z, Y, X) float32.
+ * Weights are ranked as given: affogato's wrapper-level transform (invert_repulsive_weights, bias_cut) is applied by
+ * oracle/mws.py:affogato_weights before the call; `affs` is (n_offsets, Z, Y, X) float32.
+ * Labels: affogato returns union-find root ids (+1 with a mask), which depend on its internals; the canonical numbering
+ * here is build-defined, the PARTITION is the portable claim (oracle/mws.py:same_partition).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -46,8 +49,9 @@ static int has_mutex(int64_t* parent, list_t* mtx, int64_t ra, int64_t rb) {
   return 0;
 }
 
-int mws_oracle(const float* affs, const int32_t* offsets, int32_t n_off, int32_t n_attr, const int32_t shape[3],
-               const int32_t strides[3], const uint8_t* mask, uint64_t* labels) {
+/* origin: global coordinate of voxel (0,0,0) — the stride grid is (coordinate + origin) % stride == 0 (a slab of a larger volume) */
+int mws_oracle2(const float* affs, const int32_t* offsets, int32_t n_off, int32_t n_attr, const int32_t shape[3],
+                const int32_t strides[3], const int32_t origin[3], const uint8_t* mask, uint64_t* labels) {
   const int64_t Z = shape[0], Y = shape[1], X = shape[2], N = Z * Y * X;
   if (N <= 0) return 0;
   edge_t* edges = (edge_t*)malloc((size_t)N * (size_t)n_off * sizeof(edge_t));
@@ -58,7 +62,7 @@ int mws_oracle(const float* affs, const int32_t* offsets, int32_t n_off, int32_t
     for (int64_t z = 0; z < Z; ++z) for (int64_t y = 0; y < Y; ++y) for (int64_t x = 0; x < X; ++x) {
       const int64_t z2 = z + oz, y2 = y + oy, x2 = x + ox;
       if (z2 < 0 || z2 >= Z || y2 < 0 || y2 >= Y || x2 < 0 || x2 >= X) continue;
-      if (k >= n_attr && ((z % strides[0]) || (y % strides[1]) || (x % strides[2]))) continue;
+      if (k >= n_attr && (((z + origin[0]) % strides[0]) || ((y + origin[1]) % strides[1]) || ((x + origin[2]) % strides[2]))) continue;
       const int64_t u = (z * Y + y) * X + x, v = (z2 * Y + y2) * X + x2;
       if (mask && (!mask[u] || !mask[v])) continue;
       edges[ne].w = affs[(int64_t)k * N + u];
@@ -100,4 +104,10 @@ int mws_oracle(const float* affs, const int32_t* offsets, int32_t n_off, int32_t
   for (int64_t i = 0; i < N; ++i) free(mtx[i].v);
   free(mtx); free(parent); free(size); free(edges);
   return 0;
+}
+
+int mws_oracle(const float* affs, const int32_t* offsets, int32_t n_off, int32_t n_attr, const int32_t shape[3],
+               const int32_t strides[3], const uint8_t* mask, uint64_t* labels) {
+  const int32_t origin[3] = {0, 0, 0};
+  return mws_oracle2(affs, offsets, n_off, n_attr, shape, strides, origin, mask, labels);
 }

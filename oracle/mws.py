@@ -29,24 +29,49 @@ def prepare(affs, sep=3, mask_thresh=0.5, max_affinity_value=1.0):
     return w.astype(np.float32), mask
 
 
-def compute_mws_segmentation(weights, offsets, n_attractive, strides=(1, 1, 1), mask=None):
+def affogato_weights(weights, n_attractive, invert_repulsive_weights=True, bias_cut=0.):
+    """What affogato's Python wrapper does to the weights before ranking them (published source, not vendored here:
+    `if invert_repulsive_weights: weights[n:] *= -1; weights[n:] += 1` then `weights[:n] += bias_cut`), in float32."""
+    w = np.array(weights, dtype=np.float32, copy=True)
+    if invert_repulsive_weights:
+        w[n_attractive:] *= -1
+        w[n_attractive:] += 1
+    w[:n_attractive] += np.float32(bias_cut)
+    return w
+
+
+def compute_mws_segmentation(weights, offsets, n_attractive, strides=(1, 1, 1), mask=None, invert_repulsive_weights=True,
+                             bias_cut=0., origin=(0, 0, 0)):
+    """affogato's call (defaults included: the reference passes neither invert_repulsive_weights nor bias_cut,
+    segment.py:197-199) on the C restatement, which ranks the transformed weights as given."""
     lib = C.CDLL(build_oracle.build())
-    w = np.ascontiguousarray(weights, dtype=np.float32)
+    w = np.ascontiguousarray(affogato_weights(weights, n_attractive, invert_repulsive_weights, bias_cut))
     off = np.ascontiguousarray(offsets, dtype=np.int32)
     shape = (C.c_int32 * 3)(*w.shape[1:])
     st = (C.c_int32 * 3)(*[int(s) for s in strides])
+    org = (C.c_int32 * 3)(*[int(s) for s in origin])
     m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
     out = np.zeros(w.shape[1:], dtype=np.uint64)
-    rc = lib.mws_oracle(w.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_int32(off.shape[0]),
-                        C.c_int32(n_attractive), shape, st, None if m is None else m.ctypes.data_as(C.c_void_p),
-                        out.ctypes.data_as(C.c_void_p))
+    rc = lib.mws_oracle2(w.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_int32(off.shape[0]),
+                         C.c_int32(n_attractive), shape, st, org, None if m is None else m.ctypes.data_as(C.c_void_p),
+                         out.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise MemoryError("mws oracle")
     return out
 
 
-def mws_python(weights, offsets, n_attractive, strides=(1, 1, 1), mask=None):
+def same_partition(a, b):
+    """True iff two label volumes describe the same partition (0 = background in both) — the portable parity claim."""
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    if a.shape != b.shape or not np.array_equal(a == 0, b == 0):
+        return False
+    pairs = np.unique(np.stack([a, b], 1), axis=0)
+    return len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+
+
+def mws_python(weights, offsets, n_attractive, strides=(1, 1, 1), mask=None, invert_repulsive_weights=True, bias_cut=0.):
     """Independent pure-Python Kruskal (explicit cluster/mutex sets) for tiny volumes: checks the C restatement."""
+    weights = affogato_weights(weights, n_attractive, invert_repulsive_weights, bias_cut)
     Z, Y, X = weights.shape[1:]
     N = Z * Y * X
     edges = []

@@ -32,7 +32,8 @@ class rg_conv_params(C.Structure):
 
 class rg_mws_params(C.Structure):
     _fields_ = [("shape", C.c_int32 * 3), ("n_offsets", C.c_int32), ("n_attractive", C.c_int32),
-                ("strides", C.c_int32 * 3), ("randomize_strides", C.c_int32)]
+                ("strides", C.c_int32 * 3), ("randomize_strides", C.c_int32), ("invert_repulsive_weights", C.c_int32),
+                ("bias_cut", C.c_float), ("origin", C.c_int32 * 3)]
 
 
 _P = C.POINTER

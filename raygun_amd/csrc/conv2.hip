@@ -267,16 +267,13 @@ static void launch_igemm2(Igemm2Args& a, hipStream_t s) {
   else hipLaunchKernelGGL((igemm2_kernel<BM, FN, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
 }
 
-// K alignment (per tap) the engine wants for the packed weights of this problem: 64 -> igemm2, 32 -> igemm.
+// K alignment (per tap) the engine wants for the packed weights of this problem: 64 -> igemm2/3/4, 1 -> FLAT (igemm4 / thin).
 extern "C" int rg_conv3d_kalign(int cin, int cout) {
   const int lanes = round_up(cin, 8);
-  // direct-fragment kernel (K = taps*lanes in 8-lane groups): thin output AND thin input — with wide inputs the four
-  // k-groups of a step read 16-byte pieces 2*lanes bytes apart and the tiled kernel wins (84->12: 1.12 vs 1.38 ms)
-  if (cout <= 16 && lanes <= 32 && getenv("RG_DIRECT")) return 8;
   // BK = 64 per tap wastes (round_up(lanes,64)-lanes)/lanes of the MFMA work: accept up to ~12 %
   if (lanes >= 64 && (round_up(lanes, 64) - lanes) * 8 <= lanes && round_up(cout, 16) >= 48) return 64;
-  // everything else: K flattened across taps in 8-lane pieces (igemm4 FLAT); RG_KALIGN32=1 keeps the old per-tap 32 kernel
-  return getenv("RG_KALIGN32") ? 32 : 1;
+  // everything else: K flattened across taps in 8-lane pieces (igemm4 FLAT)
+  return 1;
 }
 
 int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p,

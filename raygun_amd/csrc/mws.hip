@@ -34,14 +34,15 @@ __device__ __forceinline__ unsigned order_desc(float w) {
 // atomic (one per wavefront was the bottleneck: 262 144 serialised atomics on one counter at 256^3).
 #define MWS_EDGE_THREADS 1024
 __global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys,
-                                                                    unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx) {
+                                                                    unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx,
+                                                                    int oz, int oy, int ox, int invert, float bias) {
   __shared__ unsigned wave_base[MWS_EDGE_THREADS / 64];
   const unsigned N = (unsigned)((long)Z * Y * X);
   const unsigned u = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 valid = 0;
   if (u < N && (!mask || mask[u])) {
     const int x = (int)(u % (unsigned)X), y = (int)((u / (unsigned)X) % (unsigned)Y), z = (int)(u / ((unsigned)X * (unsigned)Y));
-    const int kmax = (z % sz == 0 && y % sy == 0 && x % sx == 0) ? n_off : n_attr;
+    const int kmax = ((z + oz) % sz == 0 && (y + oy) % sy == 0 && (x + ox) % sx == 0) ? n_off : n_attr;
     for (int k = 0; k < kmax; ++k) {
       const int z2 = z + offsets[3 * k], y2 = y + offsets[3 * k + 1], x2 = x + offsets[3 * k + 2];
       if ((unsigned)z2 < (unsigned)Z && (unsigned)y2 < (unsigned)Y && (unsigned)x2 < (unsigned)X &&
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(const float
   while (valid) {
     const int k = __builtin_ctzll(valid); valid &= valid - 1;
     const unsigned id = (unsigned)k * N + u;
-    keys[pos++] = ((u64)order_desc(affs[id]) << 32) | (u64)id;
+    float w = affs[id];  // affogato's wrapper, in float32: w[n_attr:] = w[n_attr:] * -1 + 1 (invert_repulsive_weights), w[:n_attr] += bias_cut
+    if (k >= n_attr) { if (invert) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f); }
+    else w = __fadd_rn(w, bias);
+    keys[pos++] = ((u64)order_desc(w) << 32) | (u64)id;
   }
 }
 
@@ -372,10 +376,12 @@ struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_pairs, off_op
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
   if (!p || p->shape[0] <= 0 || p->shape[1] <= 0 || p->shape[2] <= 0 || p->n_offsets <= 0 || p->n_attractive < 0 ||
-      p->n_attractive > p->n_offsets || p->strides[0] <= 0 || p->strides[1] <= 0 || p->strides[2] <= 0 || p->randomize_strides)
+      p->n_attractive > p->n_offsets || p->strides[0] <= 0 || p->strides[1] <= 0 || p->strides[2] <= 0 || p->randomize_strides || p->origin[0] < 0 || p->origin[1] < 0 ||
+      p->origin[2] < 0 || !(p->bias_cut == p->bias_cut))
     return -1;
   q->N = (long)p->shape[0] * p->shape[1] * p->shape[2];
   if ((double)q->N * p->n_offsets >= 4294967295.0 || q->N >= 0x7fffffff) return -2;  // 32-bit edge ids
+  // voxels on the stride grid: an upper bound for any origin
   const long grid = (long)((p->shape[0] + p->strides[0] - 1) / p->strides[0]) * ((p->shape[1] + p->strides[1] - 1) / p->strides[1]) *
                     ((p->shape[2] + p->strides[2] - 1) / p->strides[2]);
   q->ne_max = q->N * p->n_attractive + grid * (p->n_offsets - p->n_attractive);
@@ -435,20 +441,21 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
   RG_CHECK_LAUNCH();
   if (p->n_offsets > 64) RG_FAIL(RG_ERR_UNSUPPORTED, "mws: at most 64 offsets");
   hipLaunchKernelGGL(mws_edges_kernel, dim3((unsigned)((q.N + MWS_EDGE_THREADS - 1) / MWS_EDGE_THREADS)), dim3(MWS_EDGE_THREADS), 0, st, affs, offsets, mask, keys, count, Z, Y, X, p->n_offsets,
-                     p->n_attractive, p->strides[0], p->strides[1], p->strides[2]);
+                     p->n_attractive, p->strides[0], p->strides[1], p->strides[2], p->origin[0], p->origin[1], p->origin[2],
+                     p->invert_repulsive_weights, p->bias_cut);
   RG_CHECK_LAUNCH();
   size_t tb = q.tmp_bytes;
   if (rocprim::radix_sort_keys(tmp, tb, keys, keys2, (size_t)q.ne_max, 0, 64, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: radix sort failed");
   {
     // persistent grid with hand-made grid barriers: every workgroup must be resident, hence the cooperative launch
-    static int wgs = 0;
-    if (!wgs) {
+    // sized per call from the device the caller made current: no process-wide state (header contract)
+    int wgs = 0;
+    {
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mws_rounds_kernel, MWS_THREADS, 0) != hipSuccess || cus * per_cu < 1)
         RG_FAIL(RG_ERR_HIP, "mws: cannot size the persistent grid");
       wgs = cus * per_cu < MWS_MAX_WGS ? cus * per_cu : MWS_MAX_WGS;
-      if (const char* e = getenv("RG_MWS_WGS")) { const int v = atoi(e); if (v >= 1 && v <= cus * per_cu) wgs = v; }
     }
     const u64* kp = keys2; const unsigned* cp = count; const int* op = offsets;
     u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
@@ -456,7 +463,6 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     MwsCtl* ctl = (MwsCtl*)(w + q.off_cnt + 64);
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
-    if (const char* e = getenv("RG_MWS_WMUL")) { const int v = atoi(e); if (v >= 1 && (unsigned)v * wgs * MWS_THREADS <= cap) wmul = v; }
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
     void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul};
     rg_set_kernel_name("mws_rounds_kernel");
@@ -464,13 +470,6 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
       RG_FAIL(RG_ERR_HIP, "mws: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
     rg_prof_mark(st);
-    if (getenv("RG_MWS_STATS")) {
-      MwsCtl h; unsigned ne = 0;
-      hipStreamSynchronize(st);
-      hipMemcpy(&h, ctl, sizeof(h), hipMemcpyDeviceToHost); hipMemcpy(&ne, count, 4, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[mws] N=%ld edges=%u rounds=%u pool=%u stalled=%u wgs=%d visits=%llu  A %.2f ms  B %.2f ms  C %.2f ms\n", q.N, ne, h.rounds,
-              h.pool_used, h.stalled, wgs, h.visits, h.t[0] * 1e-5, h.t[1] * 1e-5, h.t[2] * 1e-5);
-    }
   }
   hipLaunchKernelGGL(mws_first_kernel, dim3(blocks), dim3(256), 0, st, S, mask, first, q.N);
   RG_CHECK_LAUNCH();

@@ -181,6 +181,23 @@ def _triple(v):
     return (int(v),) * 3 if isinstance(v, int) else tuple(int(a) for a in v)
 
 
+def invalidate_packed(obj):
+    """Drop the packed bf16 operands cached on a parameter (or on every parameter of a module).  The caches key on
+    (tensor._version, data_ptr); in-place writes THROUGH `.data` (`w.data.normal_()`, `w.data.copy_()`, EMA / clipping code)
+    do not bump `_version`, so whoever writes that way after a first forward must call this — raygun_amd's own writers
+    (networks.utils.init_weights, BaseCompetentLoss.clamp_weights) do.  Optimisers, load_state_dict and every ordinary
+    in-place op under no_grad bump the version and need nothing."""
+    if isinstance(obj, torch.nn.Module):
+        for p in obj.parameters():
+            invalidate_packed(p)
+        return
+    if hasattr(obj, "_rg_pack_cache"):
+        try:
+            del obj._rg_pack_cache
+        except AttributeError:
+            pass
+
+
 def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     """fp32 torch-layout weight -> packed bf16 [rows16][taps][red32]; cached on the tensor per version."""
     key = (int(swap), tuple(k0), tuple(kstep), None if ntap is None else tuple(ntap))

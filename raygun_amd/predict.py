@@ -181,9 +181,67 @@ def predict_zarr(model, source_path, source_dataset, dest_path=None, output_ds=N
     if world and world > 1:
         if torch.distributed.is_initialized():
             torch.distributed.barrier()
+        elif (rank or 0) != 0:
+            raise RuntimeError("raygun_amd.predict_zarr: world > 1 without an initialised process group — ranks other than 0 "
+                               "cannot know when the destination datasets exist (initialise torch.distributed, or let rank "
+                               "0 prepare them first and pass them to predict_volume)")
         dests = [zarrio.open_ds(dest_path, name, "a") for name in names]
     predict_volume(model, src, input_shape, output_shape, read_size, crop, ndims, scaleShift_input,
                    [d.dtype for d in dests], out_channels, rank, world, device, destinations=dests)
+    return dests
+
+
+def predict(render_config_path=None, rank=None, world=None):
+    """`raygun-predict render.json` — mirror of raygun.predict.predict (reference: src/raygun/predict.py:16-192).
+
+    Same render-config keys and defaults (:27-55), destination path / dataset naming (:57-68), ROI arithmetic (:73-108) and
+    destination datasets (:111-125: one per output_ds entry over the source's ROI, voxel size and offset, dtype = the
+    source's unless out_specs overrides it, chunked by the write ROI, deleted first) — through raygun_amd.zarrio instead of
+    daisy.  The daisy task + worker pool (:130-167) is replaced by the static block partition: this process (or, under
+    torch.distributed, every rank) runs raygun_amd.torch.predict.worker.worker over its share.  `launch_command`
+    (LSF submission) is ignored; the neuroglancer view script (:171-189) is written as the reference does.
+    Returns the list of destination arrays."""
+    import logging
+    import sys
+    from . import zarrio
+    from .torch.predict.worker import destination_names, read_render_config, shape_args, worker
+    if render_config_path is None:
+        render_config_path = sys.argv[1]
+    logger = logging.getLogger(__name__)
+    render_config, train_config = read_render_config(render_config_path)
+    if rank is None and world is None:
+        rank, _, world = parallel.init_from_env()
+    source = zarrio.open_ds(render_config["source_path"], render_config["source_dataset"])
+    dest_path, output_ds = destination_names(render_config)
+    shapes = shape_args(render_config, train_config)
+    _, write, _ = roi_geometry(render_config["ndims"], **shapes)
+    out_specs = render_config["out_specs"]
+    if (rank or 0) == 0:
+        for dest_dataset in output_ds:
+            these_specs = {"dtype": source.dtype, "num_channels": None}
+            if out_specs is not None and dest_dataset in out_specs:
+                these_specs.update(out_specs[dest_dataset])
+            zarrio.prepare_ds(dest_path, dest_dataset, source.shape[-3:], source.voxel_size, these_specs["dtype"], write_size=write,
+                              num_channels=these_specs["num_channels"], offset=source.offset, delete=True)
+    if world and world > 1:
+        if not torch.distributed.is_initialized():
+            raise RuntimeError("raygun_amd.predict: world > 1 needs an initialised torch.distributed process group")
+        torch.distributed.barrier()
+    logger.info("Running blockwise prediction...")
+    dests, n = worker(render_config_path, rank=rank, world=world)
+    if world and world > 1:
+        torch.distributed.barrier()
+    if (rank or 0) == 0:
+        source_path = render_config["source_path"]
+        view_script = os.path.join(dest_path, f"view_{os.path.basename(source_path).rstrip('.n5').rstrip('.zarr')}.ng")
+        for dest_dataset in output_ds:
+            if not os.path.exists(view_script):
+                with open(view_script, "w") as f:
+                    f.write(f"neuroglancer -f {source_path} -d {render_config['source_dataset']} -f {dest_path} -d {dest_dataset} ")
+            else:
+                with open(view_script, "a") as f:
+                    f.write(f"{dest_dataset} ")
+    logger.info("Done.")
     return dests
 
 
@@ -265,3 +323,7 @@ class _Drain:
             print(f"[drain] download {self.stats[0]:.3f} s, scatter {self.stats[1]:.3f} s, producer blocked {self.stats[2]:.3f} s", flush=True)
         if self.err is not None:
             raise self.err
+
+
+if __name__ == "__main__":
+    predict()

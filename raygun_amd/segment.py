@@ -35,13 +35,28 @@ def build_neighborhood(neighborhood=None, n_diagonals=8):
     return nb
 
 
-def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, strides=None, mask=None,
-                             randomize_strides=False, device=None, as_tensor=False):
-    """GPU mutex watershed.  weights: (n_offsets, Z, Y, X) float32 edge weights (numpy or torch), offsets: (n_offsets, 3),
-    mask: (Z, Y, X) bool or None.  Returns a uint64 ndarray (Z, Y, X) like affogato (0 = masked out); with as_tensor=True
-    the labels stay on the device (int64 tensor, same bits) and nothing is copied back."""
+def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, strides=None, randomize_strides=False,
+                             invert_repulsive_weights=True, bias_cut=0., mask=None, algorithm="kruskal", device=None,
+                             as_tensor=False, origin=(0, 0, 0)):
+    """GPU mutex watershed with affogato's call signature (affogato.segmentation.compute_mws_segmentation as published:
+    weights, offsets, number_of_attractive_channels, strides=None, randomize_strides=False, invert_repulsive_weights=True,
+    bias_cut=0., mask=None, algorithm='kruskal'; the reference's call site is segment.py:197-199).
+
+    weights: (n_offsets, Z, Y, X) float32 (numpy or torch), offsets: (n_offsets, 3), mask: (Z, Y, X) bool or None (True =
+    valid).  As in affogato the weights are transformed before they are ranked, in float32: the repulsive channels become
+    `w * -1 + 1` when `invert_repulsive_weights` (the default — so the reference, which already passes 1 - affinity there,
+    ranks its repulsive edges by the twice-inverted value), then `bias_cut` is added to the attractive channels.  Unlike
+    affogato the caller's array is left untouched.  Only algorithm='kruskal' is built ('prim' yields the same partition for
+    distinct weights; its tie order is affogato-internal).  Returns a uint64 ndarray (Z, Y, X), 0 = masked out; labels are
+    1 + rank of the cluster's first voxel in raster order — affogato returns union-find root ids (+1 with a mask), so
+    only the PARTITION is the portable claim (parity unpinned).  as_tensor=True keeps the labels on the device
+    (int64 tensor, same bits).  `origin`: global coordinate of voxel (0,0,0) for the stride grid (slabs of a larger volume)."""
     if randomize_strides:
         raise NotImplementedError("raygun_amd: randomize_strides is not built (the reference passes strides only)")
+    if algorithm != "kruskal":
+        if algorithm == "prim":
+            raise NotImplementedError("raygun_amd: algorithm='prim' is not built (the reference uses the default, 'kruskal')")
+        raise AssertionError("Unsupported algorithm, %s" % algorithm)  # affogato asserts
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("raygun_amd.compute_mws_segmentation runs on the MI355X only (no CPU fallback)")
@@ -59,7 +74,9 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
     for i in range(3):
         p.shape[i] = w.shape[1 + i]
         p.strides[i] = 1 if strides is None else int(strides[i])
+        p.origin[i] = int(origin[i])
     p.n_offsets, p.n_attractive, p.randomize_strides = w.shape[0], int(number_of_attractive_channels), 0
+    p.invert_repulsive_weights, p.bias_cut = int(bool(invert_repulsive_weights)), float(bias_cut)
     labels = torch.zeros(tuple(w.shape[1:]), dtype=torch.int64, device=dev)
     if labels.numel() == 0:
         return labels if as_tensor else labels.cpu().numpy().astype(np.uint64)
@@ -115,7 +132,7 @@ def segment_blocks(weights, offsets, sep, strides, mask, block_shape, rank=0, wo
     for bi in shard_blocks(len(blocks), rank, world):
         z, y, x = blocks[bi]
         sl = (slice(z, min(z + bz, Z)), slice(y, min(y + by, Y)), slice(x, min(x + bx, X)))
-        seg = compute_mws_segmentation(weights[(slice(None),) + sl], offsets, sep, strides, None if mask is None else mask[sl])
+        seg = compute_mws_segmentation(weights[(slice(None),) + sl], offsets, sep, strides, mask=None if mask is None else mask[sl], origin=(z, y, x))
         out[sl] = np.where(seg > 0, seg + np.uint64(bi) * np.uint64(bz * by * bx), 0)
     return out
 

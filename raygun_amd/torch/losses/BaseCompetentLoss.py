@@ -36,6 +36,7 @@ class BaseCompetentLoss(torch.nn.Module):
         for module in net.model:
             if hasattr(module, "weight") and hasattr(module.weight, "data"):
                 module.weight.data = module.weight.data.clamp(min, max)
+                ops.invalidate_packed(module.weight)
 
     def l1(self, real, pred):
         """SmoothL1(beta=1, mean) runs as the fused kernel; any other user-supplied criterion is called as is."""

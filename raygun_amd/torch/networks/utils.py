@@ -56,6 +56,8 @@ def init_weights(net, init_type="normal", init_gain=0.02, nonlinearity="relu"):
 
     print("initialize network with %s" % init_type)
     net.apply(init_func)
+    from ... import ops
+    ops.invalidate_packed(net)  # the writes above go through .data: they do not bump the version the packed-operand caches key on
 
 
 class NoiseBlock(torch.nn.Module):

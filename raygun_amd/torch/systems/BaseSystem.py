@@ -178,27 +178,75 @@ class BaseSystem:
     def setup_optimization(self):
         raise NotImplementedError()
 
+    def batch_specs(self):
+        """{array name: (shape, lo, hi)} of one synthetic batch — provided by subclasses."""
+        raise NotImplementedError()
+
     def setup_datapipes(self):
-        """The reference builds gunpowder graphs here (io/*DataPipe.py, out of scope); raygun_amd systems take arrays."""
+        """The reference builds gunpowder graphs here (io/*DataPipe.py, out of scope).  Here: `self.batches`, an iterable of
+        batch dicts (train/data.py) — random crops of the config's `sources` where that is defined for the system, counter-hash
+        synthetic volumes when the config says `"synthetic_data": true` or names no sources."""
+        from ..train.data import SyntheticBatches
         self.datapipes = {}
+        rank = getattr(self, "distributed", (0, 0, 1))[0]
+        if getattr(self, "synthetic_data", False) or not getattr(self, "sources", None):
+            self.batches = SyntheticBatches(self.batch_specs(), self.device, getattr(self, "random_seed", None) or 42, rank)
+        else:
+            self.batches = self.source_batches(rank)
+
+    def source_batches(self, rank):
+        raise NotImplementedError(f"raygun_amd.{type(self).__name__}: training from `sources` needs the reference's target "
+                                  "generation (SURVEY.md 8(f4), not built); set \"synthetic_data\": true or pass batches=")
 
     def setup_trainer(self):
         from ..train import Trainer
+        kw = getattr(self, "train_kwargs", None) or {}
+        for k in ("checkpoint_basename", "save_every", "log_every"):  # newer configs keep these under train_kwargs (BaseSystem.py:286-293)
+            if k in kw:
+                setattr(self, k, kw[k])
         self.trainer = Trainer(self)
 
+    @property
+    def device(self):
+        import torch as _t
+        d = getattr(self, "distributed", None)
+        return _t.device("cuda", d[1] if d is not None else _t.cuda.current_device())
+
     def build_system(self):
-        """BaseSystem.py:312-318."""
+        """BaseSystem.py:312-318 (networks, model, optimisation, data pipes, trainer) + what gunpowder's Train node does when
+        it starts: modules to the GPU, latest checkpoint restored.  Under data parallelism (`self.distributed`, set by
+        raygun_amd.train) rank 0's initial weights are broadcast and the optimisation gets a GradSync."""
+        from ... import parallel
+        if not torch.cuda.is_available():
+            raise RuntimeError("raygun_amd: training runs on the MI355X only (no CPU fallback)")
         self.setup_networks()
         self.setup_model()
-        self.setup_optimization()
+        dev = self.device
+        self.model.to(dev)
+        for name in ("netD1", "netD2"):
+            if hasattr(self, name):
+                getattr(self, name).to(dev)
+        world = getattr(self, "distributed", (0, 0, 1))[2]
+        grad_sync = None
+        if world > 1:
+            for m in [self.model] + [getattr(self, n) for n in ("netD1", "netD2") if hasattr(self, n)]:
+                parallel.broadcast_parameters(m)
+            grad_sync = parallel.GradSync()
+        self.setup_optimization(grad_sync) if grad_sync is not None else self.setup_optimization()
+        if hasattr(self.loss, "to"):
+            self.loss.to(dev)
         self.setup_datapipes()
         self.setup_trainer()
+        if getattr(self, "checkpoint", None):
+            self.trainer.load_checkpoint(self.checkpoint)
 
     def train(self, batches=None):
-        """BaseSystem.py:320-326."""
+        """BaseSystem.py:320-328: num_epochs from train_kwargs when present."""
         if not hasattr(self, "trainer"):
             self.build_system()
-        return self.trainer.train(self.num_epochs, batches=batches)
+        kw = getattr(self, "train_kwargs", None) or {}
+        self.batch = self.trainer.train(kw.get("num_epochs", getattr(self, "num_epochs", None)), batches=batches)
+        return self.batch
 
 
 def _deepcopy(v):

@@ -85,3 +85,13 @@ class CycleGAN(BaseSystem):
                                        self.optimizer_D, self.ndims, grad_sync=grad_sync, **self.loss_kwargs)
         else:
             raise NotImplementedError("Unexpected Loss Style. Accepted options are 'cycle' or 'split'")
+
+    def batch_specs(self):
+        shp = (self.batch_size, self.gnet_kwargs.get("input_nc", 1)) + (self.side_length,) * self.ndims
+        return {"real_A": (shp, -1.0, 1.0), "real_B": (shp, -1.0, 1.0)}
+
+    def source_batches(self, rank):
+        """Random crops of sources["A"/"B"] ({"path", "real_name"}, systems/CycleGAN.py:236-248), scaled as CycleDataPipe does."""
+        from ..train.data import ZarrCropBatches
+        return ZarrCropBatches(self.sources, self.side_length, self.ndims, self.batch_size, self.device,
+                               getattr(self, "random_seed", None) or 42, rank)

@@ -53,3 +53,11 @@ class MTLSD(BaseSystem):
         self.optimizer = get_base_optimizer(self.optim_type)(params=self.model.parameters(), **self.optim_kwargs)
         self.loss = WeightedMSELoss_MTLSD(**self.loss_kwargs)
         self.grad_sync = grad_sync
+
+    def batch_specs(self):
+        """Names = MTLSDModel.forward's argument + WeightedMSELoss_MTLSD.forward's extras (MTLSDModel.py:52, loss :27-35)."""
+        n = self.batch_size
+        i, o = tuple(self.input_shape), tuple(self.output_shape)
+        na = self.model_kwargs.get("num_affs", 3)
+        return {"raw": ((n, 1) + i, -1.0, 1.0), "gt_lsds": ((n, 10) + o, 0.0, 1.0), "lsds_weights": ((n, 10) + o, 1.0, 1.0),
+                "gt_affs": ((n, na) + o, 0.0, 1.0), "affs_weights": ((n, na) + o, 1.0, 1.0)}

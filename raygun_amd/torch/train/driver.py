@@ -1,11 +1,17 @@
-"""Minimal train-step driver reproducing the call order of the reference's gp.torch.Train node
-(torch/train/BaseTrain.py:63-75,167-178; reconstructed in SURVEY.md §3.1/§3.2), without gunpowder:
+"""Train-step driver reproducing the call order of the reference's gp.torch.Train node
+(torch/train/BaseTrain.py:63-75,167-178; reconstructed in SURVEY.md 3.1/3.2), without gunpowder:
 
     optimizer.zero_grad(); outs = model(**inputs); loss = loss_fn(*loss_inputs); loss.backward(); optimizer.step()
     model.update_status(step); loss.update_status(step); checkpoint every save_every
 
 Batches are dicts of arrays named after the model's forward arguments plus the loss's extra arguments
 (BaseTrain.py:42-60).  Data-parallel gradient averaging (no reference counterpart) hooks in through `grad_sync`.
+
+Checkpoints are what gunpowder's Train node writes — a torch.save'd dict with `model_state_dict` and
+`optimizer_state_dict` under <checkpoint_basename>_checkpoint_<iteration> (the schema BaseSystem.load_saved_model reads,
+BaseSystem.py:118-121; PARITY UNPINNED beyond those two keys: the gunpowder fork is not under /root/reference) — plus
+`iteration` and, for the CycleGAN whose BaseDummyOptimizer is a parameter-less Module (state_dict() == {}), the wrapped
+optimisers' and schedulers' state under `optimizers` / `schedulers`, so a resumed run continues with its Adam moments.
 """
 import inspect
 import os
@@ -34,6 +40,13 @@ def train_step(model, loss_fn, optimizer, batch, grad_sync=None):
     return loss, named
 
 
+def _named_optimizers(optimizer):
+    """The real optimisers behind the system's `optimizer`: itself, or the attributes of a BaseDummyOptimizer."""
+    if isinstance(optimizer, torch.optim.Optimizer):
+        return {"optimizer": optimizer}
+    return {k: v for k, v in vars(optimizer).items() if isinstance(v, torch.optim.Optimizer)}
+
+
 class Trainer:
     def __init__(self, system):
         self.system = system
@@ -42,7 +55,10 @@ class Trainer:
     def train(self, iterations, batches=None):
         s = self.system
         if batches is None:
-            raise RuntimeError("raygun_amd.Trainer: pass an iterable of batches (the gunpowder data pipes are out of scope)")
+            batches = getattr(s, "batches", None)
+        if batches is None:
+            raise RuntimeError("raygun_amd.Trainer: no batch source (pass `batches=` or give the config `sources` / "
+                               "\"synthetic_data\": true; the gunpowder data pipes are out of scope)")
         last = None
         for batch in batches:
             if self.iteration >= iterations:
@@ -52,14 +68,41 @@ class Trainer:
             for obj in (s.model, s.loss):
                 if hasattr(obj, "update_status"):
                     obj.update_status(self.iteration)
-            if getattr(s, "save_every", None) and self.iteration % s.save_every == 0:
+            if getattr(s, "save_every", None) and self.iteration % s.save_every == 0 and self._is_writer():
                 self.save_checkpoint()
             last = (loss, outs)
         return last
+
+    def _is_writer(self):
+        d = getattr(self.system, "distributed", None)
+        return d is None or d[0] == 0
 
     def save_checkpoint(self):
         s = self.system
         os.makedirs(os.path.dirname(s.checkpoint_basename) or ".", exist_ok=True)
         path = f"{s.checkpoint_basename}_checkpoint_{self.iteration}"
-        torch.save({"model_state_dict": s.model.state_dict(), "iteration": self.iteration}, path)
+        ck = {"model_state_dict": s.model.state_dict(), "optimizer_state_dict": s.optimizer.state_dict(), "iteration": self.iteration}
+        if not isinstance(s.optimizer, torch.optim.Optimizer):
+            ck["optimizers"] = {k: o.state_dict() for k, o in _named_optimizers(s.optimizer).items()}
+            ck["schedulers"] = {k: sch.state_dict() for k, sch in getattr(s.optimizer, "schedulers", {}).items()}
+        torch.save(ck, path)
         return path
+
+    def load_checkpoint(self, path):
+        """Model weights, optimiser moments, scheduler state and the iteration counter of a checkpoint written above (a
+        reference checkpoint restores what it holds: model + optimizer_state_dict)."""
+        s = self.system
+        ck = torch.load(path, map_location=None if torch.cuda.is_available() else torch.device("cpu"), weights_only=False)
+        s.model.load_state_dict(ck["model_state_dict"] if "model_state_dict" in ck else ck)
+        if isinstance(s.optimizer, torch.optim.Optimizer):
+            if ck.get("optimizer_state_dict"):
+                s.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        else:
+            for k, o in _named_optimizers(s.optimizer).items():
+                if k in ck.get("optimizers", {}):
+                    o.load_state_dict(ck["optimizers"][k])
+            for k, sch in getattr(s.optimizer, "schedulers", {}).items():
+                if k in ck.get("schedulers", {}):
+                    sch.load_state_dict(ck["schedulers"][k])
+        self.iteration = int(ck.get("iteration", getattr(s, "iteration", 0) or 0))
+        return ck

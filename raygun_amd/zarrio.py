@@ -60,6 +60,31 @@ class Attributes(dict):
         self._flush()
 
 
+class _ChunkLock:
+    """flock() on <container>/.locks/<hash of the chunk path>: exclusive across processes and threads on one node."""
+    _tl = None
+
+    def __init__(self, chunk_path):
+        import hashlib
+        root = os.path.dirname(chunk_path)
+        while root and not os.path.exists(os.path.join(root, ".zarray")):
+            root = os.path.dirname(root)
+        d = os.path.join(root or os.path.dirname(chunk_path), ".locks")
+        os.makedirs(d, exist_ok=True)
+        self.path = os.path.join(d, hashlib.sha1(chunk_path.encode()).hexdigest()[:16])
+
+    def __enter__(self):
+        import fcntl
+        self.fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o644)
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        os.close(self.fd)
+
+
 class Array:
     def __init__(self, path, mode="r"):
         self.path, self.mode = path, mode
@@ -177,12 +202,17 @@ class Array:
             dst = tuple(slice(max(a, o) - o, min(b, o + c) - o) for a, b, o, c in zip(lo, hi, c0, self.chunks))
             whole = all(s.start == 0 and s.stop == c for s, c in zip(dst, self.chunks))
             if whole:
-                ch = value[src]
-            else:  # read-modify-write; cells of an edge chunk beyond the array bounds keep whatever they held
+                self._write_chunk(idx, value[src])
+                continue
+            # read-modify-write; cells of an edge chunk beyond the array bounds keep whatever they held.  Block-wise predict
+            # writes ROIs that start at `context`, so neighbouring blocks — possibly other ranks' — share chunks: the RMW is
+            # serialised per chunk with an advisory file lock (the reference gets the same exclusion from daisy's
+            # read_write_conflict=True scheduling, predict.py:159).
+            with _ChunkLock(self._chunk_path(idx)):
                 ch = self._read_chunk(idx)
                 ch = np.full(self.chunks, self._fill(), dtype=self.dtype) if ch is None else ch.copy()
                 ch[dst] = value[src]
-            self._write_chunk(idx, ch)
+                self._write_chunk(idx, ch)
 
     def __len__(self):
         return self.shape[0]

@@ -51,16 +51,42 @@ def test_oracle_edge_cases():
     ((48, 48, 48), (1, 1, 1), False, False), ((40, 48, 56), (2, 2, 2), True, True), ((64, 64, 64), (4, 4, 4), True, False),
     ((56, 56, 56), (1, 1, 1), True, True), ((72, 72, 72), (10, 10, 10), False, True)])
 def test_gpu_labels_bit_exact(shape, strides, use_mask, structured):
+    """Bit-exact against the build's own CPU restatement (oracle/mws.c — PARITY UNPINNED against affogato itself, whose label
+    values are union-find internals; the partition is the portable claim and is asserted separately), for both settings of
+    affogato's invert_repulsive_weights (default True = what segment.py:197-199 gets) and a non-zero bias_cut."""
     from raygun_amd.segment import compute_mws_segmentation
     w = synth.uniform((8,) + shape, 11, 0, 1)
     if structured:
-        w = (0.7 * blobs(shape, 2)[None] + 0.3 * w).astype(np.float32)
-        w[3:] = 1 - w[3:]
+        w = (0.7 * blobs(shape, 2)[None] + 0.3 * w).astype(np.float32)  # raw affinities: high = same object, every channel
     mask = (synth.uniform(shape, 12, 0, 1) > 0.2) if use_mask else None
-    ref = O.compute_mws_segmentation(w, NB8, 3, strides, mask)
-    got = compute_mws_segmentation(w, NB8, 3, strides, mask)
-    assert got.dtype == np.uint64 and got.shape == ref.shape
-    assert (got == ref).all(), f"{int((got != ref).sum())} of {ref.size} labels differ"
+    keep = w.copy()
+    for inv, bias in ((True, 0.0), (False, 0.0), (True, 0.125)):
+        ww = w.copy()
+        if structured and not inv:
+            ww[3:] = 1 - ww[3:]      # the caller inverts instead
+        ref = O.compute_mws_segmentation(ww, NB8, 3, strides, mask, invert_repulsive_weights=inv, bias_cut=bias)
+        got = compute_mws_segmentation(ww, NB8, 3, strides, mask=mask, invert_repulsive_weights=inv, bias_cut=bias)
+        assert got.dtype == np.uint64 and got.shape == ref.shape
+        assert (got == ref).all(), f"invert={inv} bias={bias}: {int((got != ref).sum())} of {ref.size} labels differ"
+        assert O.same_partition(got, ref)
+    assert np.array_equal(w, keep)  # the caller's weights are not modified (affogato modifies them in place)
+
+
+def test_affogato_weight_transform_and_partition_helper():
+    """oracle.affogato_weights = the float32 arithmetic of affogato's wrapper; the reference pipeline (segment.py:188-199)
+    therefore ranks repulsive edges by fl(1 - fl(1 - a)), attractive ones by fl(1 - fl(1 - a)) too (segment.py:193-194)."""
+    a = synth.uniform((5, 3, 3, 3), 1, 0, 1).astype(np.float32)
+    w = O.affogato_weights(a, 2)
+    assert np.array_equal(w[:2], a[:2]) and np.array_equal(w[2:], (a[2:] * np.float32(-1)) + np.float32(1))
+    assert np.array_equal(O.affogato_weights(a, 2, False, 0.25)[:2], a[:2] + np.float32(0.25))
+    ww, _ = O.prepare(a.copy(), 2)
+    both = O.affogato_weights(ww, 2)
+    assert np.array_equal(both[2:], np.float32(1) - (np.float32(1) - a[2:]))
+    l1 = np.array([[1, 1, 2], [0, 3, 3]]); l2 = np.array([[7, 7, 4], [0, 9, 9]]); l3 = np.array([[7, 7, 7], [0, 9, 9]])
+    assert O.same_partition(l1, l2) and not O.same_partition(l1, l3) and not O.same_partition(l1, np.where(l1 == 0, 5, l1))
+    tiny = synth.uniform((8, 3, 4, 3), 2, 0, 1)
+    for inv in (True, False):
+        assert (O.compute_mws_segmentation(tiny, NB8, 3, (1, 1, 1), None, inv, 0.1) == O.mws_python(tiny, NB8, 3, (1, 1, 1), None, inv, 0.1)).all()
 
 
 @pytest.mark.gpu
@@ -98,8 +124,10 @@ def test_gpu_ties_and_empty():
     from raygun_amd.segment import compute_mws_segmentation
     # every weight equal: the tie order (ascending edge id) decides everything
     w = np.full((8, 5, 6, 7), 0.5, np.float32)
-    assert (compute_mws_segmentation(w, NB8, 3, (1, 1, 1), None) == O.compute_mws_segmentation(w, NB8, 3, (1, 1, 1), None)).all()
+    assert (compute_mws_segmentation(w, NB8, 3, (1, 1, 1), mask=None) == O.compute_mws_segmentation(w, NB8, 3, (1, 1, 1), None)).all()
     m0 = np.zeros((5, 6, 7), bool)
-    assert compute_mws_segmentation(w, NB8, 3, (1, 1, 1), m0).max() == 0
+    assert compute_mws_segmentation(w, NB8, 3, (1, 1, 1), mask=m0).max() == 0
+    with pytest.raises(NotImplementedError):
+        compute_mws_segmentation(w, NB8, 3, algorithm="prim")
     with pytest.raises(ValueError):
         compute_mws_segmentation(w[:5], NB8, 3)

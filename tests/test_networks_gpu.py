@@ -184,3 +184,43 @@ def test_mtlsd_100_affinities_and_loss():
     assert l2rel(P["unet.r_conv.0.0.conv_pass.2.bias"].grad, fx["g_last_bias"]) <= 4e-2
     big = P["unet.l_conv.3.conv_pass.2.weight"].grad.reshape(-1)[torch.from_numpy(fx["g_big_idx"]).to(dev)]
     assert l2rel(big, fx["g_big_val"]) <= 0.15  # 181 M-element wgrad behind 8 ReLU layers (mask flips, see module docstring)
+
+
+def test_mtlsd_196_sampled():
+    """The HEADLINE config (config U at 196^3 -> 104^3, the shape bench.py times) against the reference-generated fixture
+    tests/golden/mtlsd_196_sampled.npz (tests/golden/make_golden.py:fx_mtlsd): 4096 sampled affinities/LSDs, their sums, the
+    loss and three gradients.  This is the only place the 196^3 host dispatch (FM tile choice, split-K round counts,
+    flat-plane wgrad, 192-row tiles, sub-pixel upsample-conv at the real crop offsets) is parity-checked end to end."""
+    from raygun_amd.torch.models import MTLSDModel
+    from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
+    fx = np.load(os.path.join(G, "mtlsd_196_sampled.npz"))
+    dev = torch.device("cuda")
+    m = MTLSDModel()
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 51))
+    m = m.to(dev)
+    raw = T(synth.uniform((1, 1, 196, 196, 196), 52)).to(dev)
+    affs, lsds = m(raw)
+    assert tuple(affs.shape) == (1, 3, 104, 104, 104) and tuple(lsds.shape) == (1, 10, 104, 104, 104)
+    gt_l = T(synth.uniform(tuple(lsds.shape), 53, 0, 1)).to(dev)
+    gt_a = T(synth.uniform(tuple(affs.shape), 54, 0, 1)).to(dev)
+    loss = WeightedMSELoss_MTLSD()(lsds, gt_l, torch.ones_like(lsds), affs, gt_a, torch.ones_like(affs))
+    loss.backward()
+    flat = torch.cat([affs.detach().reshape(-1), lsds.detach().reshape(-1)])
+    got = flat[torch.from_numpy(fx["out_idx"]).to(dev)].cpu().numpy()
+    assert l2rel(got, fx["out_val"]) <= 1.5e-2
+    assert float(np.abs(got - fx["out_val"]).max()) <= 4e-2          # post-sigmoid values in (0, 1)
+    sums = np.array([float(affs.double().sum()), float(lsds.double().sum())])
+    assert np.all(np.abs(sums - fx["out_sum"]) <= 2e-3 * np.abs(fx["out_sum"]))
+    assert abs(float(loss.detach()) - float(fx["loss"])) <= 2e-2 * float(fx["loss"])
+    P = dict(m.named_parameters())
+    assert l2rel(P["aff_head.conv_pass.0.weight"].grad, fx["g_aff_w"]) <= 3e-2
+    assert l2rel(P["unet.r_conv.0.0.conv_pass.2.bias"].grad, fx["g_last_bias"]) <= 4e-2
+    big = P["unet.l_conv.3.conv_pass.2.weight"].grad.reshape(-1)[torch.from_numpy(fx["g_big_idx"]).to(dev)]
+    assert l2rel(big, fx["g_big_val"]) <= 0.15  # 181 M-element wgrad behind 8 ReLU layers (mask flips, see module docstring)
+    # every gradient tensor: its sum against the reference's (grad_sums = [sum, sum|.|] per parameter): a dispatch bug in any
+    # one layer (a dropped tile, a split counted twice) moves these by O(1); bf16 mask flips move them by a few percent of sum|.|
+    gs = json.loads(str(fx["grad_sums"]))
+    for k, (s1, sabs) in gs.items():
+        g = P[k].grad.double()
+        assert abs(float(g.sum()) - s1) <= 0.08 * sabs, (k, float(g.sum()), s1, sabs)
+        assert abs(float(g.abs().sum()) - sabs) <= 0.15 * sabs, (k, float(g.abs().sum()), sabs)

@@ -289,30 +289,79 @@ def test_fused_adam_refreshes_packed_forward_operand(cin, cout):
 @pytest.mark.parametrize("gs,fs,target", [((9, 9, 9), (20, 20, 20), (18, 18, 18)), ((9, 10, 11), (22, 21, 23), (16, 18, 20)),
                                            ((8, 9, 8), (16, 17, 15), (13, 15, 11)), ((10, 9, 9), (24, 18, 20), (15, 17, 13))])
 def test_upcat_conv3d_equals_upsample_crop_concat_conv(gs, fs, target):
-    """ops.upcat_conv3d (27 -> 8 taps on the upsampled channels, depth-to-space) against the plain composition it replaces
-    (torch fp32 on bf16-exact operands): output and all four gradients, for even and odd crop offsets."""
+    """ops.upcat_conv3d (27 -> 8 taps on the upsampled channels, depth-to-space) against the plain composition it replaces,
+    evaluated by torch in fp32 ON THE CPU (the oracle side: no GPU library in the reference path) on bf16-exact operands:
+    output and all four gradients, for even and odd crop offsets."""
     from raygun_amd import ops
     dev = torch.device("cuda")
     cf, cg, cout = 16, 64, 24
     torch.manual_seed(0)
-    f = torch.randn(1, cf, *fs, device=dev).bfloat16().float().requires_grad_()
-    g = torch.randn(1, cg, *gs, device=dev).bfloat16().float().requires_grad_()
-    w = (torch.randn(cout, cf + cg, 3, 3, 3, device=dev) * 0.05).bfloat16().float().requires_grad_()
-    b = torch.randn(cout, device=dev).requires_grad_()
-    up = torch.nn.functional.interpolate(g, scale_factor=2, mode="nearest")
-    x = torch.cat([ops.center_crop(f, target), ops.center_crop(up, target)], 1)
-    ref = torch.tanh(torch.nn.functional.conv3d(x, w, b))
-    go = torch.randn_like(ref).bfloat16().float()
+    f0 = bf(torch.randn(1, cf, *fs)); g0 = bf(torch.randn(1, cg, *gs))
+    w0 = bf(torch.randn(cout, cf + cg, 3, 3, 3) * 0.05); b0 = torch.randn(cout)
+    f, g, w, b = (t.clone().requires_grad_() for t in (f0, g0, w0, b0))
+    up = F.interpolate(g, scale_factor=2, mode="nearest")
+    cc = lambda t: t[..., (t.shape[2] - target[0]) // 2:(t.shape[2] - target[0]) // 2 + target[0],  # noqa: E731
+                     (t.shape[3] - target[1]) // 2:(t.shape[3] - target[1]) // 2 + target[1],
+                     (t.shape[4] - target[2]) // 2:(t.shape[4] - target[2]) // 2 + target[2]]
+    ref = torch.tanh(F.conv3d(torch.cat([cc(f), cc(up)], 1), w, b))
+    go = bf(torch.randn(ref.shape))
     rg = torch.autograd.grad(ref, (f, g, w, b), go)
-    got = ops.upcat_conv3d(f, g, target, w, b, "tanh")
+    fd, gd, wd, bd = (t.clone().to(dev).requires_grad_() for t in (f0, g0, w0, b0))
+    got = ops.upcat_conv3d(fd, gd, target, wd, bd, "tanh")
     assert tuple(got.shape) == tuple(ref.shape)
-    gg = torch.autograd.grad(got, (f, g, w, b), go.to(got.dtype) if got.dtype != go.dtype else go)
+    gg = torch.autograd.grad(got, (fd, gd, wd, bd), go.to(dev).to(got.dtype))
+
     def close(a, r, tol):
-        a, r = a.float(), r.float()
+        a, r = a.float().cpu(), r.float()
         assert (a - r).abs().max().item() <= tol * r.abs().max().item() + 1e-6, ((a - r).abs().max().item(), r.abs().max().item())
     close(got, ref, 3e-2)  # pre-activations of magnitude ~10 rounded to bf16 twice
     for a, r in zip(gg, rg):
         close(a, r, 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,mid,P,k,pad,sp,act", [(16, 16, 1, 7, 3, (10, 11, 12), "tanh"), (64, 64, 1, 7, 0, (12, 12, 14), "none"),
+                                                    (24, 32, 2, 3, 1, (6, 7, 8), "none"), (8, 8, 1, 7, 3, (9, 9, 9), "sigmoid")])
+def test_conv3d_linear_pair_equals_two_layers(cin, mid, P, k, pad, sp, act):
+    """ops.conv3d_linear_pair — the generator tail Conv3d(ngf, ngf, 7) + Conv3d(ngf, output_nc, 1) evaluated as ONE composed
+    convolution (rg_diag_sum / rg_diag_spread for P == 1, the one-hot (1,1,KW) gather otherwise) — against torch's
+    two-layer evaluation in fp32 on the CPU: output and the gradients of x, w_a, b_a, w_b, b_b."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    x = bf(torch.randn(2, cin, *sp)); wa = bf(torch.randn(mid, cin, k, k, k) * (1.0 / (cin * k ** 3) ** 0.5)); ba = torch.randn(mid) * 0.1
+    wb = bf(torch.randn(P, mid, 1, 1, 1) * (1.0 / mid ** 0.5)); bb = torch.randn(P) * 0.1
+    afn = {"none": lambda t: t, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    ref_in = [t.clone().requires_grad_(True) for t in (x, wa, ba, wb, bb)]
+    yr = afn(F.conv3d(F.conv3d(ref_in[0], ref_in[1], ref_in[2], 1, pad), ref_in[3], ref_in[4]))
+    g = bf(torch.randn(yr.shape))
+    yr.backward(g)
+    my_in = [t.clone().to(dev).requires_grad_(True) for t in (x, wa, ba, wb, bb)]
+    y = ops.leave(ops.conv3d_linear_pair(my_in[0], my_in[1], my_in[2], my_in[3], my_in[4], pad, act, 0.0))
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(g.to(dev).to(y.dtype))
+    errs = {"y": relerr(y, yr)}
+    for name, a, b in zip("x wa ba wb bb".split(), my_in, ref_in):
+        errs["g_" + name] = relerr(a.grad, b.grad)
+    check(errs, 2e-2)  # the composed weight W' = w_b . w_a is rounded to bf16 once more than the two-layer evaluation's operands
+
+
+@pytest.mark.gpu
+def test_diag_spread_sum_are_exact_adjoint_gathers():
+    """rg_diag_spread / rg_diag_sum (in-plane taps <-> channels) are pure data movement + an fp32 sum: exact against numpy
+    indexing on bf16-exact data, both signs."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    kh, kw = 3, 5
+    x = rnd((2, 1, 4, 9, 11), 31)
+    oh, ow = 9 - kh + 1, 11 - kw + 1
+    y = ops._DiagSpread.apply(ops.to_cl(x.to(dev)), kh, kw, 1, oh, ow)
+    want = torch.stack([x[:, 0, :, a:a + oh, b:b + ow] for a in range(kh) for b in range(kw)], 1)
+    assert torch.equal(y.float().cpu(), want)
+    z = rnd((2, kh * kw, 4, 9, 11), 32)
+    s = ops._DiagSum.apply(ops.to_cl(z.to(dev)), kh, kw, 1, oh, ow, None)
+    want = sum(z[:, a * kw + b, :, a:a + oh, b:b + ow] for a in range(kh) for b in range(kw))[:, None]
+    assert relerr(s, want) <= 2 ** -8
 
 
 @pytest.mark.gpu
@@ -343,47 +392,70 @@ def test_fork_and_crop_gradients():
 @pytest.mark.gpu
 def test_wide_transposed_conv_subpixel_path():
     """Stride-2 / k3 / pad-1 transposed convolutions with >= 192 input channels run as one 8*Cout-channel convolution +
-    depth-to-space (ops._scatter_conv fast path): ConvTranspose3d forward and the input gradient of a strided Conv3d, against torch."""
-    import torch.nn.functional as F
+    depth-to-space (ops._scatter_conv fast path): ConvTranspose3d forward and the input gradient of a strided Conv3d, against
+    torch fp32 on the CPU."""
     from raygun_amd import ops
     dev = torch.device("cuda")
     torch.manual_seed(3)
-    x = torch.randn(1, 192, 5, 6, 7, device=dev).bfloat16().float().requires_grad_()
-    w = (torch.randn(192, 24, 3, 3, 3, device=dev) * 0.05).bfloat16().float().requires_grad_()
-    b = torch.randn(24, device=dev)
-    ref = torch.tanh(F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1))
-    got = ops.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1, act="tanh")
+    x0 = bf(torch.randn(1, 192, 5, 6, 7)); w0 = bf(torch.randn(192, 24, 3, 3, 3) * 0.05); b0 = torch.randn(24)
+    x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+    ref = torch.tanh(F.conv_transpose3d(x, w, b0, stride=2, padding=1, output_padding=1))
+    xd, wd = x0.clone().to(dev).requires_grad_(), w0.clone().to(dev).requires_grad_()
+    got = ops.conv_transpose3d(xd, wd, b0.to(dev), stride=2, padding=1, output_padding=1, act="tanh")
     assert tuple(got.shape) == (1, 24, 10, 12, 14)
-    assert (got.float() - ref).abs().max().item() <= 2e-2
-    go = torch.randn_like(ref).bfloat16().float()
-    for a, r in zip(torch.autograd.grad(got, (x, w), go), torch.autograd.grad(ref, (x, w), go)):
-        assert (a.float() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6
+    assert (got.float().cpu() - ref).abs().max().item() <= 2e-2
+    go = bf(torch.randn(ref.shape))
+    for a, r in zip(torch.autograd.grad(got, (xd, wd), go.to(dev).to(got.dtype)), torch.autograd.grad(ref, (x, w), go)):
+        assert (a.float().cpu() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6
     # strided conv: its backward-data is the same scatter with 192 source channels
-    xs = torch.randn(1, 16, 10, 12, 8, device=dev).bfloat16().float().requires_grad_()
-    ws = (torch.randn(192, 16, 3, 3, 3, device=dev) * 0.05).bfloat16().float()
-    gs = torch.randn(1, 192, 5, 6, 4, device=dev).bfloat16().float()
+    xs0 = bf(torch.randn(1, 16, 10, 12, 8)); ws = bf(torch.randn(192, 16, 3, 3, 3) * 0.05); gs = bf(torch.randn(1, 192, 5, 6, 4))
+    xs = xs0.clone().requires_grad_()
     (rg,) = torch.autograd.grad(F.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
-    (gg,) = torch.autograd.grad(ops.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
-    assert (gg.float() - rg).abs().max().item() <= 2e-2 * rg.abs().max().item()
+    xsd = xs0.clone().to(dev).requires_grad_()
+    yd = ops.conv3d(xsd, ws.to(dev), None, stride=2, padding=1)
+    (gg,) = torch.autograd.grad(yd, xsd, gs.to(dev).to(yd.dtype))
+    assert (gg.float().cpu() - rg).abs().max().item() <= 2e-2 * rg.abs().max().item()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cout", [144, 128])
 def test_igemm4_192_row_tiles(cout, monkeypatch):
     """The 192-row tile (FM = 3) of igemm4 is only picked for large grids; force it (RG_FM=3) on a small problem: forward and
-    backward-data against torch."""
-    import torch.nn.functional as F
+    backward-data against torch fp32 on the CPU."""
     from raygun_amd import ops
     monkeypatch.setenv("RG_FM", "3")
     dev = torch.device("cuda")
     torch.manual_seed(5)
-    x = torch.randn(1, 64, 9, 10, 11, device=dev).bfloat16().float().requires_grad_()
-    w = (torch.randn(cout, 64, 3, 3, 3, device=dev) * 0.05).bfloat16().float()
-    b = torch.randn(cout, device=dev)
+    x0 = bf(torch.randn(1, 64, 9, 10, 11)); w = bf(torch.randn(cout, 64, 3, 3, 3) * 0.05); b = torch.randn(cout)
+    x = x0.clone().requires_grad_()
     ref = F.conv3d(x, w, b)
-    got = ops.conv3d(x, w, b)
-    assert (got.float() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
-    go = torch.randn_like(ref).bfloat16().float()
+    xd = x0.clone().to(dev).requires_grad_()
+    got = ops.conv3d(xd, w.to(dev), b.to(dev))
+    assert (got.float().cpu() - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
+    go = bf(torch.randn(ref.shape))
     (rg,) = torch.autograd.grad(ref, x, go)
-    (gg,) = torch.autograd.grad(got, x, go)
-    assert (gg.float() - rg).abs().max().item() <= 1.5e-2 * rg.abs().max().item()
+    (gg,) = torch.autograd.grad(got, xd, go.to(dev).to(got.dtype))
+    assert (gg.float().cpu() - rg).abs().max().item() <= 1.5e-2 * rg.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_packed_weight_cache_invalidation():
+    """The packed bf16 operands are cached per (version, data_ptr).  `.data` writes do not bump the version: init_weights
+    (which writes through .data, networks/utils.py:55-73) and ops.invalidate_packed must make the next forward see the new
+    weights; ordinary in-place ops under no_grad bump the version by themselves."""
+    from raygun_amd import hipnn, ops
+    from raygun_amd.torch.networks.utils import init_weights
+    dev = torch.device("cuda")
+    conv = hipnn.Conv3d(8, 16, 3).to(dev)
+    x = rnd((1, 8, 6, 6, 6), 3).to(dev)
+    y0 = conv(x).clone()
+    init_weights(conv, "normal", 0.5)
+    y1 = conv(x).clone()
+    ref = F.conv3d(x.cpu(), bf(conv.weight.detach().cpu()), conv.bias.detach().cpu())
+    assert relerr(y1, ref) <= TOL and not torch.allclose(y0, y1)
+    conv.weight.data.mul_(2.0)            # invisible to the version counter ...
+    ops.invalidate_packed(conv)           # ... so the writer says so
+    assert relerr(conv(x), F.conv3d(x.cpu(), bf(conv.weight.detach().cpu()), conv.bias.detach().cpu())) <= TOL
+    with torch.no_grad():
+        conv.weight.mul_(0.5)             # bumps the version: nothing to do
+    assert relerr(conv(x), F.conv3d(x.cpu(), bf(conv.weight.detach().cpu()), conv.bias.detach().cpu())) <= TOL

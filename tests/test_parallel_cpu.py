@@ -65,3 +65,69 @@ def test_single_process_is_noop():
     parallel.GradSync()([p])
     assert p.grad.tolist() == [2.0, 2.0, 2.0]
     assert list(parallel.shard_blocks(5, rank=0, world=1)) == [0, 1, 2, 3, 4]
+
+
+def _tiny_cyclegan(split, grad_sync):
+    """The build's CycleModel + Link/SplitCycleLoss host logic around plain torch nets (CPU: 'vanilla' GAN mode and a
+    user-supplied L1 keep every op on torch — the HIP kernels have no CPU path)."""
+    import itertools
+    from raygun_amd.torch.losses import LinkCycleLoss, SplitCycleLoss
+    from raygun_amd.torch.models import CycleModel
+    torch.manual_seed(3)
+    G = lambda: torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv3d(4, 1, 3, padding=1))  # noqa: E731
+    D = lambda: torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, stride=2), torch.nn.LeakyReLU(0.2), torch.nn.Conv3d(4, 1, 3))  # noqa: E731
+    g1, g2, d1, d2 = G(), G(), D(), D()
+    model = CycleModel(g1, g2, None, None, split=split)
+    oD = torch.optim.Adam(itertools.chain(d1.parameters(), d2.parameters()), lr=1e-2)
+    if split:
+        oG1, oG2 = torch.optim.Adam(g1.parameters(), lr=1e-2), torch.optim.Adam(g2.parameters(), lr=1e-2)
+        loss = SplitCycleLoss(d1, g1, d2, g2, oG1, oG2, oD, 3, l1_loss=torch.nn.L1Loss(), gan_mode="vanilla", grad_sync=grad_sync)
+    else:
+        oG = torch.optim.Adam(itertools.chain(g1.parameters(), g2.parameters()), lr=1e-2)
+        loss = LinkCycleLoss(d1, g1, d2, g2, oG, oD, 3, l1_loss=torch.nn.L1Loss(), gan_mode="vanilla", grad_sync=grad_sync)
+    return model, loss, [g1, g2, d1, d2]
+
+
+def _cyc_worker(rank, world, port, out, split):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from raygun_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(11)
+    A, B = torch.randn(world, 1, 8, 8, 8, generator=g), torch.randn(world, 1, 8, 8, 8, generator=g)
+    calls = []
+    sync = parallel.GradSync()
+
+    def counted(params):
+        calls.append(len(params)); sync(params)
+    model, loss, nets = _tiny_cyclegan(split, counted)
+    for it in range(2):
+        fB, cB, fA, cA = model(real_A=A[rank:rank + 1], real_B=B[rank:rank + 1])
+        loss(A[rank:rank + 1], fA, cA, B[rank:rank + 1], fB, cB)
+    # the same two steps in one process on the concatenated batch
+    rmodel, rloss, rnets = _tiny_cyclegan(split, None)
+    for it in range(2):
+        fB, cB, fA, cA = rmodel(real_A=A, real_B=B)
+        rloss(A, fA, cA, B, fB, cB)
+    err = max(float((p - q).abs().max()) for n, m in zip(nets, rnets) for p, q in zip(n.parameters(), m.parameters()))
+    out.put((rank, err, calls, [float(p.detach().double().sum()) for n in nets for p in n.parameters()]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_cyclegan_grad_sync_hook_equals_big_batch(split):
+    """The CycleGAN losses call `grad_sync` once per optimiser step (Link: G1 u G2, then D — LinkCycleLoss.py:121-135,61-85;
+    Split: G1, G2, D).  World size 2 over gloo, 2 iterations: the weights equal a single-process run on the concatenated
+    batch (SURVEY.md 8d config 4's correctness criterion) and are identical across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cyc_worker, args=(r, 2, port, q, split)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] < 5e-6 for r in res), res
+    assert len(res[0][2]) == (3 if split else 2) * 2      # hook invocations: per optimiser, per iteration
+    assert res[0][3] == res[1][3]

@@ -1,5 +1,7 @@
 """Block runner: ROI arithmetic (CPU) and block-wise == whole-volume prediction on the GPU (valid U-Net: translation
 equivariant on the write grid, so tiling must reproduce the single-pass result wherever blocks write)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -95,3 +97,41 @@ def test_on_disk_flow_equals_in_memory(tmp_path):
     from oracle import mws as O
     ww, m = O.prepare(mem[0].copy(), 3, 0.3, 1.0)
     assert np.array_equal(seg, O.compute_mws_segmentation(ww, O.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m))
+
+
+@pytest.mark.gpu
+def test_predict_real_geometry_196_to_104_vs_cpu_oracle():
+    """Config 5's predict half at the REAL block geometry: MTLSDModel(num_affs=20) (config U, 259 M parameters), read ROI
+    196^3 -> write ROI 104^3, context 46, a 300^3 uint8 volume = 2 x 2 x 2 blocks (worker.py:94-160 per block).  Oracle:
+    oracle.torch_ref.MTLSDModel (fp32, CPU, pinned to the reference by tests/golden/mtlsd_*.npz) run with the identical block
+    decomposition and the worker's arithmetic ((x - min)/max, *2-1, centre crop, float32 destination).  Tolerance: the bf16
+    storage policy of DESIGN 4 (post-sigmoid values in (0,1))."""
+    from oracle import torch_ref as O
+    from raygun_amd.torch.models import MTLSDModel
+    dev = torch.device("cuda")
+    m, ref = MTLSDModel(num_affs=20), O.MTLSDModel(num_affs=20)
+    sd = synth.fill_state_dict(m.state_dict(), 51)
+    m.load_state_dict(sd); ref.load_state_dict(sd)
+    m = m.to(dev).eval(); ref.eval()
+    vol = (synth.uniform((300, 300, 300), 77, 0, 1) * 255).astype(np.uint8)
+    dests, n = P.predict_volume(m, vol, input_shape=196, output_shape=104, scaleShift_input=[2, -1],
+                                out_dtypes=[np.float32, np.float32])
+    assert n == 8 and dests[0].shape == (20, 300, 300, 300) and dests[1].shape == (10, 300, 300, 300)
+    read, write, ctx = P.roi_geometry(3, 196, 104)
+    blocks = P.enumerate_blocks(vol.shape, read, write, ctx)
+    assert blocks == [(z, y, x) for z in (46, 150) for y in (46, 150) for x in (46, 150)]
+    torch.set_num_threads(max(1, (os.cpu_count() or 2)))
+    worst = 0.0
+    with torch.no_grad():
+        for (wz, wy, wx) in blocks:
+            data = torch.from_numpy(vol[wz - 46:wz + 150, wy - 46:wy + 150, wx - 46:wx + 150].astype(np.float32))[None, None]
+            data = (data - 0.0) / 255.0 * 2 - 1
+            affs, lsds = ref(data)
+            for got, want in ((dests[0], affs[0].numpy()), (dests[1], lsds[0].numpy())):
+                g = got[:, wz:wz + 104, wy:wy + 104, wx:wx + 104]
+                err = float(np.abs(g - want).max())
+                worst = max(worst, err)
+                assert err <= 4e-2, (wz, wy, wx, err)
+                assert np.sqrt(((g - want) ** 2).sum() / (want ** 2).sum()) <= 1.5e-2
+    assert (dests[0][:, :46] == 0).all() and (dests[0][:, 254:] == 0).all()  # nothing written outside the write ROIs
+    print(f"predict 196->104 x 8 blocks: worst |diff| vs fp32 CPU oracle {worst:.2e}")

@@ -20,10 +20,10 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
         affs = affs_for(n, kind)
         w, m = O.prepare(affs.copy())
         wt = torch.from_numpy(w).cuda(); mt = torch.from_numpy(m.astype(np.uint8)).cuda()
-        S.compute_mws_segmentation(wt[:, :16, :16, :16].contiguous(), nb, 3, (10, 10, 10), mt[:16, :16, :16].contiguous())
-        S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mt)
+        S.compute_mws_segmentation(wt[:, :16, :16, :16].contiguous(), nb, 3, (10, 10, 10), mask=mt[:16, :16, :16].contiguous())
+        S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mask=mt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        seg = S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mt)
+        seg = S.compute_mws_segmentation(wt, nb, 3, (10, 10, 10), mask=mt)
         torch.cuda.synchronize(); tg = time.perf_counter() - t0
         line = f"n={n} {kind}: gpu {tg*1e3:.1f} ms = {n**3/tg/1e6:.2f} Mvox/s ({n**3*88/tg/1e9:.2f} GB/s) segments={int(seg.max())} masked={1-m.mean():.2f}"
         if n <= int(os.environ.get("RG_ORACLE_MAX", "160")):

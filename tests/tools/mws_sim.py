@@ -91,14 +91,14 @@ if __name__ == "__main__":
     shape = (10, 10, 10); strides = (1, 1, 1)
     for seed in range(3):
         w = synth.uniform((8,) + shape, 11 + seed, 0, 1)
-        ref = O.compute_mws_segmentation(w, NB8, 3, strides, None).reshape(-1)
+        ref = O.compute_mws_segmentation(w, NB8, 3, strides, None, invert_repulsive_weights=False).reshape(-1)
         for kw in (dict(early_rep=False, quiet=False), dict(early_rep=True, quiet=False), dict(early_rep=False, quiet=True, mutex_exc=False),
                    dict(early_rep=False, quiet=True, mutex_exc=True), dict()):
             got, rounds = sim(w, NB8, 3, strides, None, **kw)
             print(seed, kw, "rounds", rounds, "diff", int((got != ref).sum()), flush=True)
     shape = (16, 16, 16)
     w = synth.uniform((8,) + shape, 11, 0, 1)
-    ref = O.compute_mws_segmentation(w, NB8, 3, strides, None).reshape(-1)
+    ref = O.compute_mws_segmentation(w, NB8, 3, strides, None, invert_repulsive_weights=False).reshape(-1)
     for WIN in (65536, 4096):
         got, rounds = sim(w, NB8, 3, strides, None, WIN=WIN)
         print("16^3 WIN", WIN, "rounds", rounds, "diff", int((got != ref).sum()), flush=True)

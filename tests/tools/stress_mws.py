@@ -26,7 +26,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
         w[3:] = (0.5 + 0.5 * w[3:]).astype(np.float32)
     mask = (rng.random(shape) > 0.15) if rng.integers(2) else None
     ref = O.compute_mws_segmentation(w, nb, 3, strides, mask)
-    got = compute_mws_segmentation(w, nb, 3, strides, mask)
+    got = compute_mws_segmentation(w, nb, 3, strides, mask=mask)
     n += 1
     if not (ref == got).all():
         bad += 1

@@ -1,4 +1,4 @@
-"""PCIe-inclusive block-wise predict: numpy source on the host, numpy destinations (the reference's flow).  scratch."""
+"""PCIe-inclusive block-wise predict: numpy source on the host, numpy destinations (the reference's flow).  tools."""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: bash scratch/pmc_conv.sh <tag> <shape list> <counters...>
+# usage: bash tools/pmc_conv.sh <tag> <shape list> <counters...>
 set -e
 TAG=$1; SH=$2; shift 2
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_$TAG -o p -- python3 $ROOT/scratch/bench_conv.py $SH > $ROOT/gpurun_out/pmc_$TAG.log 2>&1
+rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_$TAG -o p -- python3 $ROOT/tools/bench_conv.py $SH > $ROOT/gpurun_out/pmc_$TAG.log 2>&1
 cd $ROOT
 python3 - <<PY
 import csv, collections

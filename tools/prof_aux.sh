@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash scratch/prof_aux.sh <tag>  -> rocprofv3 kernel stats of the predict and segment bench workloads
+# usage (GPU box, repo root): bash tools/prof_aux.sh <tag>  -> rocprofv3 kernel stats of the predict and segment bench workloads
 set -e
 TAG=$1
 ROOT=$(pwd)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash scratch/prof_seg.sh <tag> [sizes...]  -> rocprofv3 kernel stats of tests/tools/bench_seg.py
+# usage: bash tools/prof_seg.sh <tag> [sizes...]  -> rocprofv3 kernel stats of tests/tools/bench_seg.py
 TAG=$1; shift
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (on the GPU box, from repo root): bash scratch/prof_unet.sh <tag> [workload]
+# usage (on the GPU box, from repo root): bash tools/prof_unet.sh <tag> [workload]
 set -e
 TAG=$1; WL=${2:-unet}
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o p -- python3 $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o p -- python3 $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 cd $ROOT
 python3 tools/prof_summary.py stats gpurun_out/prof_$TAG/p_kernel_stats.csv gpurun_out/prof_$TAG/summary.csv
 python3 - <<PY

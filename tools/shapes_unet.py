@@ -1,4 +1,4 @@
-"""Per-shape conv timing of the UNet 196^3 train step (scratch)."""
+"""Per-shape conv timing of the UNet 196^3 train step (tools)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
