@@ -9,6 +9,10 @@
  *   - never throws, never aborts; re-entrant across streams/devices (no global mutable state
  *     except the thread-local error string).
  *
+ * Two builds of the same sources export the same entry points: libraygun_hip.so stores activations and packed weights as
+ * bf16 (RG_BF16), libraygun_hip_f16.so (-DRG_STORE_F16) as IEEE half (RG_F16; rg_version() has bit 16 set).  Wherever "bf16" is
+ * written below, read "the build's 16-bit storage type"; a tensor of the other type is rejected with RG_ERR_BAD_SHAPE.
+ *
  * Tensor convention: activations are channels-last bf16, "NDHWC with padded lanes": logical shape
  * (N,C,D,H,W), channel stride 1, every other stride a multiple of 8 elements, base 16-byte aligned.
  * Lanes [C, lanes) of every voxel are zero (lanes = C rounded up to 8).  Strides are in elements.
@@ -31,7 +35,7 @@ enum rg_status {
   RG_ERR_HIP = -3,
   RG_ERR_WORKSPACE = -4
 };
-enum rg_dtype { RG_BF16 = 0, RG_F32 = 1, RG_U8 = 2, RG_I32 = 3, RG_U64 = 4, RG_F64 = 5 };
+enum rg_dtype { RG_BF16 = 0, RG_F32 = 1, RG_U8 = 2, RG_I32 = 3, RG_U64 = 4, RG_F64 = 5, RG_F16 = 6 };
 enum rg_act { RG_ACT_NONE = 0, RG_ACT_RELU = 1, RG_ACT_LEAKY = 2, RG_ACT_SIGMOID = 3, RG_ACT_TANH = 4 };
 
 typedef struct {
@@ -210,6 +214,26 @@ int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mas
  * rounded exactly as numpy does in float32.  affs / weights: (n_offsets, n_voxels) float32 (may not alias), mask: n_voxels bytes. */
 int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,
                    float thresh, rg_stream s);
+
+
+/* ---- slab decomposition of the mutex watershed (no reference counterpart: affogato segments one in-memory array; SURVEY.md 8e,
+ * DESIGN.md 6).  First level: rg_mws_segment per Z-slab (origin[0] = the slab's first global plane).  Second level: a mutex
+ * watershed over first-level clusters — rg_mws_cross_edges collects the grid edges from this slab into the neighbour above
+ * (dir +1) / below (dir -1) given the neighbour's H nearest planes of GLOBAL cluster ids, rg_mws_slab_mutexes the mutexes the
+ * first level left inside the slab between second-level nodes (is_node[local label]; pairs packed lo << 32 | hi, duplicates
+ * possible), rg_mws_graph runs the Kruskal pass on the merged edge list (ascending wkey, ties by ascending gid; wkey 0 = mutexes
+ * that exist before every edge) and returns rep[i] = smallest node of i's cluster, rg_mws_relabel maps labels through a table.
+ * Record arrays are caller-allocated with capacity `cap`; *count (zeroed by the caller) ends as the number of records produced
+ * (a value > cap means the arrays were too small and the surplus was dropped). */
+int rg_mws_cross_edges(const float* weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
+                       int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
+                       int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s);
+int rg_mws_slab_mutexes(const int64_t* labels, const uint8_t* is_node, const int32_t* offsets, const rg_mws_params* p, uint64_t* pairs,
+                        uint32_t* count, uint32_t cap, rg_stream s);
+int64_t rg_mws_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uint32_t* eu, const uint32_t* ev, const uint8_t* attractive,
+                 int64_t n_edges, int64_t n_nodes, int32_t* rep, void* workspace, size_t ws_bytes, rg_stream s);
+int rg_mws_relabel(int64_t* labels, const int64_t* lut, int64_t n, rg_stream s);
 
 #ifdef __cplusplus
 }

@@ -111,3 +111,43 @@ int mws_oracle(const float* affs, const int32_t* offsets, int32_t n_off, int32_t
   const int32_t origin[3] = {0, 0, 0};
   return mws_oracle2(affs, offsets, n_off, n_attr, shape, strides, origin, mask, labels);
 }
+
+/* Second level of the slab decomposition (build-defined): Kruskal mutex watershed over an explicit edge list.
+ * Order: ascending wkey (the 32-bit descending-weight key of the grid pass; 0 = a mutex that exists before every edge), ties by
+ * ascending 64-bit global edge id.  rep[i] = smallest node id in i's cluster. */
+typedef struct { uint32_t wkey; uint64_t gid; int64_t idx; } gedge_t;
+static int cmp_gedge(const void* a, const void* b) {
+  const gedge_t* x = (const gedge_t*)a; const gedge_t* y = (const gedge_t*)b;
+  if (x->wkey != y->wkey) return x->wkey < y->wkey ? -1 : 1;
+  return (x->gid > y->gid) - (x->gid < y->gid);
+}
+int mws_graph_oracle(int64_t n_nodes, int64_t n_edges, const uint32_t* wkey, const uint64_t* gid, const int64_t* eu, const int64_t* ev,
+                     const uint8_t* attr, int64_t* rep) {
+  gedge_t* e = (gedge_t*)malloc((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(gedge_t));
+  int64_t* parent = (int64_t*)malloc((size_t)n_nodes * sizeof(int64_t));
+  int64_t* size = (int64_t*)malloc((size_t)n_nodes * sizeof(int64_t));
+  list_t* mtx = (list_t*)calloc((size_t)n_nodes, sizeof(list_t));
+  if (!e || !parent || !size || !mtx) return -1;
+  for (int64_t i = 0; i < n_edges; ++i) { e[i].wkey = wkey[i]; e[i].gid = gid[i]; e[i].idx = i; }
+  qsort(e, (size_t)n_edges, sizeof(gedge_t), cmp_gedge);
+  for (int64_t i = 0; i < n_nodes; ++i) { parent[i] = i; size[i] = 1; }
+  for (int64_t j = 0; j < n_edges; ++j) {
+    const int64_t i = e[j].idx;
+    int64_t ru = find(parent, eu[i]), rv = find(parent, ev[i]);
+    if (ru == rv) continue;
+    if (attr[i]) {
+      if (has_mutex(parent, mtx, ru, rv)) continue;
+      if (size[ru] < size[rv]) { int64_t t = ru; ru = rv; rv = t; }
+      parent[rv] = ru; size[ru] += size[rv];
+      for (int64_t q = 0; q < mtx[rv].n; ++q) push(&mtx[ru], mtx[rv].v[q]);
+      free(mtx[rv].v); mtx[rv].v = NULL; mtx[rv].n = mtx[rv].cap = 0;
+    } else {
+      push(&mtx[ru], rv); push(&mtx[rv], ru);
+    }
+  }
+  for (int64_t i = 0; i < n_nodes; ++i) size[i] = -1;   /* reuse: smallest member per root */
+  for (int64_t i = 0; i < n_nodes; ++i) { const int64_t r = find(parent, i); if (size[r] < 0) size[r] = i; rep[i] = size[r]; }
+  for (int64_t i = 0; i < n_nodes; ++i) free(mtx[i].v);
+  free(mtx); free(parent); free(size); free(e);
+  return 0;
+}

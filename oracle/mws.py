@@ -118,3 +118,69 @@ def mws_python(weights, offsets, n_attractive, strides=(1, 1, 1), mask=None, inv
             seen[r] = len(seen) + 1
         labels[i] = seen[r]
     return labels.reshape(Z, Y, X)
+
+
+def _order_desc(w):
+    """The 32-bit key both passes rank by: ascending key == descending float32 weight (raygun_amd/csrc/mws.hip:order_desc)."""
+    b = np.ascontiguousarray(w, dtype=np.float32).view(np.uint32)
+    b = np.where(b & np.uint32(0x80000000), ~b, b | np.uint32(0x80000000))
+    return ~b
+
+
+def graph_mws(n_nodes, wkey, gid, eu, ev, attr):
+    lib = C.CDLL(build_oracle.build())
+    wkey = np.ascontiguousarray(wkey, np.uint32); gid = np.ascontiguousarray(gid, np.uint64)
+    eu = np.ascontiguousarray(eu, np.int64); ev = np.ascontiguousarray(ev, np.int64); attr = np.ascontiguousarray(attr, np.uint8)
+    rep = np.zeros(n_nodes, np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    if lib.mws_graph_oracle(C.c_int64(n_nodes), C.c_int64(len(wkey)), p(wkey), p(gid), p(eu), p(ev), p(attr), p(rep)) != 0:
+        raise MemoryError("graph mws oracle")
+    return rep
+
+
+def slab_mws(weights, offsets, n_attractive, strides, mask, bounds, invert_repulsive_weights=True, bias_cut=0.):
+    """CPU restatement of the two-level slab decomposition (the oracle for volumes segmented in Z-slabs, SURVEY.md
+    8e): first level = the grid oracle per slab [bounds[s], bounds[s+1]) (stride grid in global coordinates), second level =
+    graph_mws over ALL first-level clusters with (a) every valid grid edge whose ends lie in different slabs, ranked like the
+    grid pass, and (b) a pre-existing mutex (wkey 0) for every valid repulsive edge inside a slab whose ends carry different
+    labels.  No node filtering here — the GPU path's restriction to boundary-zone clusters must not change the result.
+    Labels: 1 + rank of the cluster's first voxel in global raster order."""
+    w = np.ascontiguousarray(weights, np.float32)
+    K, Z, Y, X = w.shape
+    off = np.asarray(offsets, np.int64)
+    tw = affogato_weights(w, n_attractive, invert_repulsive_weights, bias_cut)
+    lab = np.zeros((Z, Y, X), np.int64)
+    base = 0
+    slab_of = np.zeros(Z, np.int64)
+    for s in range(len(bounds) - 1):
+        z0, z1 = bounds[s], bounds[s + 1]
+        l = compute_mws_segmentation(w[:, z0:z1], offsets, n_attractive, strides, None if mask is None else mask[z0:z1],
+                                     invert_repulsive_weights, bias_cut, origin=(z0, 0, 0)).astype(np.int64)
+        lab[z0:z1] = np.where(l > 0, l + base, 0)
+        base += int(l.max())
+        slab_of[z0:z1] = s
+    n_nodes = base + 1                                          # node 0 = background, never touched
+    zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    N = Z * Y * X
+    wk, gid, eu, ev, at = [], [], [], [], []
+    for k in range(K):
+        z2, y2, x2 = zz + off[k, 0], yy + off[k, 1], xx + off[k, 2]
+        ok = (z2 >= 0) & (z2 < Z) & (y2 >= 0) & (y2 < Y) & (x2 >= 0) & (x2 < X)
+        if k >= n_attractive:
+            ok &= (zz % strides[0] == 0) & (yy % strides[1] == 0) & (xx % strides[2] == 0)
+        u = np.nonzero(ok.reshape(-1))[0]
+        v = (z2.reshape(-1)[u] * Y + y2.reshape(-1)[u]) * X + x2.reshape(-1)[u]
+        lu, lv = lab.reshape(-1)[u], lab.reshape(-1)[v]
+        keep = (lu > 0) & (lv > 0)
+        cross = slab_of[u // (Y * X)] != slab_of[v // (Y * X)]
+        sel = keep & cross
+        wk.append(_order_desc(tw[k].reshape(-1)[u[sel]])); gid.append((k * N + u[sel]).astype(np.uint64))
+        eu.append(lu[sel]); ev.append(lv[sel]); at.append(np.full(int(sel.sum()), 1 if k < n_attractive else 0, np.uint8))
+        if k >= n_attractive:
+            sel = keep & ~cross & (lu != lv)
+            wk.append(np.zeros(int(sel.sum()), np.uint32)); gid.append((k * N + u[sel]).astype(np.uint64))
+            eu.append(lu[sel]); ev.append(lv[sel]); at.append(np.zeros(int(sel.sum()), np.uint8))
+    rep = graph_mws(n_nodes, np.concatenate(wk), np.concatenate(gid), np.concatenate(eu), np.concatenate(ev), np.concatenate(at))
+    is_rep = rep == np.arange(n_nodes)
+    rank = np.cumsum(is_rep) - 1                               # node 0 is its own rep: rank 0 = background
+    return rank[rep][lab].astype(np.uint64)

@@ -9,8 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libraygun_hip.so")
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "lib", "libraygun_hip_f16.so")}  # same sources, 16-bit storage type differs
 
-RG_BF16, RG_F32, RG_U8, RG_I32, RG_U64, RG_F64 = range(6)
+RG_BF16, RG_F32, RG_U8, RG_I32, RG_U64, RG_F64, RG_F16 = range(7)
 ACT = {"none": 0, "relu": 1, "leaky": 2, "sigmoid": 3, "tanh": 4}
 
 
@@ -82,31 +83,57 @@ _SIGS = {
     "rg_mws_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "rg_mws_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "rg_mws_cross_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, _P(rg_mws_params),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rg_mws_slab_mutexes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rg_mws_graph_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "rg_mws_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                               C.c_size_t, C.c_void_p]),
+    "rg_mws_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 DECLARED = sorted(_SIGS)
-_lib = None
+_F16_ABSENT = {"rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_segment", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
+               "rg_mws_graph_workspace_bytes", "rg_mws_graph", "rg_mws_relabel"}  # no 16-bit data on the mutex-watershed path
+_libs = {}
+import threading
+_tls = threading.local()
 
 
-def lib():
-    """Load the library (once).  Raises RuntimeError if it is not built — there is no fallback."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"raygun_amd: {LIB_PATH} is missing — build it with `python -m raygun_amd.build` "
+def lib(kind="bf16"):
+    """Load (once) and return the library whose 16-bit storage type is `kind` ("bf16" | "f16").  Raises RuntimeError if it is
+    not built — there is no fallback."""
+    l = _libs.get(kind)
+    if l is None:
+        path = LIB_PATHS[kind]
+        if not os.path.exists(path):
+            raise RuntimeError(f"raygun_amd: {path} is missing — build it with `python -m raygun_amd.build` "
                                "(hipcc --offload-arch=gfx950). The HIP path has no CPU fallback.")
         import torch  # noqa: F401  (loads torch's libamdhip64 first so both share one HIP runtime)
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
+            if kind == "f16" and name in _F16_ABSENT:
+                continue
             fn = getattr(l, name)  # AttributeError => symbol missing: fail loudly
             fn.restype, fn.argtypes = res, args
-        _lib = l
-    return _lib
+        if bool(l.rg_version() >> 16) != (kind == "f16"):
+            raise RuntimeError(f"raygun_amd: {path} was not built for {kind} storage")
+        _libs[kind] = l
+    _tls.last = kind
+    return l
+
+
+_DEBUG_SYNC = bool(os.environ.get("RAYGUN_AMD_DEBUG_SYNC"))  # fault localisation: name every call on stderr, then wait for it
 
 
 def check(rc, what=""):
+    if _DEBUG_SYNC:
+        import sys
+        import torch
+        sys.stderr.write(f"[rg] {what} {lib(getattr(_tls, 'last', 'bf16')).rg_last_kernel_name().decode()}\n"); sys.stderr.flush()
+        torch.cuda.synchronize()
     if rc != 0:
-        msg = lib().rg_last_error_string().decode("utf-8", "replace")
+        msg = lib(getattr(_tls, "last", "bf16")).rg_last_error_string().decode("utf-8", "replace")
         raise RuntimeError(f"raygun_amd HIP call failed ({what}, status {rc}): {msg}")
 
 

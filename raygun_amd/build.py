@@ -1,4 +1,5 @@
-"""Build libraygun_hip.so (gfx950) in-tree with hipcc.  `python -m raygun_amd.build [--force]`."""
+"""Build libraygun_hip.so (bf16 storage) and libraygun_hip_f16.so (-DRG_STORE_F16: IEEE-half storage, same sources, same entry points)
+for gfx950 in-tree with hipcc.  `python -m raygun_amd.build [--force]`."""
 import os
 import subprocess
 import sys
@@ -8,8 +9,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libraygun_hip.so")
+LIB_F16 = os.path.join(LIBDIR, "libraygun_hip_f16.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
+VARIANTS = (("", [], LIB), ("_f16", ["-DRG_STORE_F16=1"], LIB_F16))
+F16_SKIP = {"mws.hip"}  # no 16-bit data on that path: the mutex watershed lives in the bf16 library only
 
 
 def sources():
@@ -30,35 +34,40 @@ def build(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "raygun_hip.h"))
     jobs = []
-    for f in sources():
-        src = os.path.join(CSRC, f)
-        obj = os.path.join(objdir, f[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append((src, obj))
+    objs = {v[0]: [] for v in VARIANTS}
+    for tag, defs, _ in VARIANTS:
+        for f in sources():
+            if tag and f in F16_SKIP:
+                continue
+            src = os.path.join(CSRC, f)
+            obj = os.path.join(objdir, f[:-4] + tag + ".o")
+            objs[tag].append(obj)
+            if force or _stale(obj, [src] + hdrs):
+                jobs.append((src, obj, defs))
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        src, obj, defs = job
+        cmd = [HIPCC] + FLAGS + defs + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            for (src, obj), r in ex.map(cc, jobs):
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for (src, obj, defs), r in ex.map(cc, jobs):
                 if r.returncode != 0:
                     sys.stderr.write(r.stdout + r.stderr)
-                    raise RuntimeError(f"hipcc failed on {src}")
+                    raise RuntimeError(f"hipcc failed on {src} {' '.join(defs)}")
                 if verbose:
-                    print(f"[raygun_amd.build] compiled {os.path.basename(src)}")
-    objs = [os.path.join(objdir, f[:-4] + ".o") for f in sources()]
-    if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("link failed")
-        if verbose:
-            print(f"[raygun_amd.build] linked {LIB}")
+                    print(f"[raygun_amd.build] compiled {os.path.basename(obj)}")
+    for tag, _, lib in VARIANTS:
+        if jobs or force or _stale(lib, objs[tag]):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs[tag]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError("link failed")
+            if verbose:
+                print(f"[raygun_amd.build] linked {lib}")
     return LIB
 
 

@@ -21,7 +21,21 @@ void rg_prof_mark(hipStream_t st);              // HIP event before / after the 
 #define RG_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
   rg_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return RG_ERR_HIP; } } while (0)
 
-// ---- bf16 <-> f32 (round to nearest even; NaN stays NaN) --------------------
+// ---- the 16-bit storage type of activations and packed weights -------------------------------------------------------------
+// One source, two builds: bf16 (libraygun_hip.so, the training default: fp32's exponent range) and, with -DRG_STORE_F16, IEEE half
+// (libraygun_hip_f16.so: 11 significant bits instead of 8 — the block runner's precision mode).  The kernels never
+// look inside an element except through these three definitions; `bf16_t` / `bf16x8` are the 16-bit containers in both builds,
+// v_mfma_f32_16x16x32_f16 has the bf16 form's rate, tile shapes and lane maps (MI355X_MICROARCH.md, Matrix cores).
+#ifdef RG_STORE_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 rg_h8;
+#define RG_ACT_DTYPE RG_F16
+#define RG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_h8, (a)), __builtin_bit_cast(rg_h8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }  // v_cvt_f16_f32: RNE, overflow -> inf, NaN stays NaN
+#else
+#define RG_ACT_DTYPE RG_BF16
+#define RG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// bf16 <-> f32 (round to nearest even; NaN stays NaN)
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   uint32_t u = __float_as_uint(f);
@@ -29,6 +43,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+#endif
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
   switch (act) {
@@ -63,7 +78,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Validates the activation convention and fills a CL5.  `lanes` = C rounded up to 8.
 static inline int rg_as_cl5(const rg_tensor* t, CL5* o, const char* name) {
   if (!t || !t->ptr) { rg_set_error("%s: null tensor", name); return RG_ERR_BAD_SHAPE; }
-  if (t->dtype != RG_BF16 || t->rank != 5) { rg_set_error("%s: expected bf16 rank-5 (N,C,D,H,W)", name); return RG_ERR_BAD_SHAPE; }
+  if (t->dtype != RG_ACT_DTYPE || t->rank != 5) { rg_set_error("%s: expected a rank-5 (N,C,D,H,W) tensor of this build's 16-bit type (rg_dtype %d), got dtype %d", name, (int)RG_ACT_DTYPE, (int)t->dtype); return RG_ERR_BAD_SHAPE; }
   if (t->strides[1] != 1 && t->sizes[1] != 1) { rg_set_error("%s: channel stride must be 1 (channels-last)", name); return RG_ERR_BAD_SHAPE; }
   o->p = (bf16_t*)t->ptr;
   o->N = (int)t->sizes[0]; o->C = (int)t->sizes[1]; o->D = (int)t->sizes[2]; o->H = (int)t->sizes[3]; o->W = (int)t->sizes[4];

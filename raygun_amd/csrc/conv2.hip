@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 2 : 1)) void igemm2_kernel(Igemm2
       lds_wait<NW>(wf[t % 3]);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t % 3], kk ? xf1[i] : xf0[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = RG_MFMA16(wf[t % 3], kk ? xf1[i] : xf0[i], acc[i][j]);
       // address math of stage ks+2, one DMA piece per MFMA step, in the shadow of the matrix pipe
       if constexpr (t < APW) prep_a(t); else if constexpr (t - APW < BPW) prep_b(t - APW);
       __builtin_amdgcn_sched_barrier(0);

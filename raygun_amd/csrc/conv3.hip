@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(Igemm3Args a) {
       if constexpr (t == 0) { sfor<FM>([&](auto I) { constexpr int i = decltype(I)::value; ldwait<NW>(xf0[i]); ldwait<NW>(xf1[i]); }); }
       ldwait<NW>(wf[t % 3]);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t % 3], kk ? xf1[i] : xf0[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) acc[i][j] = RG_MFMA16(wf[t % 3], kk ? xf1[i] : xf0[i], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("" ::: "memory");

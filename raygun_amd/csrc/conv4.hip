@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
       for (int i = 0; i < FM; ++i) {
         bf16x8 xf;
         __builtin_memcpy(&xf, &xa[i][kk], 16);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t % 3], xf, acc[i][j], 0, 0, 0);
+        acc[i][j] = RG_MFMA16(wf[t % 3], xf, acc[i][j]);
       }
       if constexpr (t == FN - 1) { prep_a(); load_a0(); }  // k-half 0 fragments are free: fetch those of step ks+1
     });
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
       for (int i = 0; i < FM; ++i) {
         bf16x8 f0, f1;
         __builtin_memcpy(&f0, &x[i][0], 16); __builtin_memcpy(&f1, &x[i][1], 16);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, f0, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, f1, acc[i], 0, 0, 0);
+        acc[i] = RG_MFMA16(w0, f0, acc[i]);
+        acc[i] = RG_MFMA16(w1, f1, acc[i]);
       }
     };
     (void)wl0;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void igemm_thin3_kernel(Igemm4Args a) {
         for (int i = 0; i < FM; ++i) {
           bf16x8 f;
           if (kw == 0) __builtin_memcpy(&f, &b[i], 16); else if (kw == 1) __builtin_memcpy(&f, &x1[i], 16); else __builtin_memcpy(&f, &x2[i], 16);
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, f, acc[i], 0, 0, 0);
+          acc[i] = RG_MFMA16(wv, f, acc[i]);
         }
       }
     };

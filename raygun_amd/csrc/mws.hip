@@ -224,9 +224,12 @@ __device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target
 
 __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys, const unsigned* count, const int* offsets, MwsState s,
                                                                 u64* claim, u64* pairs, uint4* win0, uint4* win1, int2* ops, MwsCtl* ctl,
-                                                                int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap, unsigned wmul) {
+                                                                int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap, unsigned wmul,
+                                                                const unsigned* perm, const unsigned* eu, const unsigned* ev, const unsigned char* eattr) {
+  // grid mode (perm == nullptr): edge id = k*N + u on the (Z,Y,X) grid, v = u + offset k.  graph mode: slot -> edge perm[slot] of an
+  // explicit edge list (eu, ev, eattr) over N = Z*Y*X abstract nodes (the second level of the slab decomposition).
   __shared__ int lin[64];
-  if (threadIdx.x < n_off && threadIdx.x < 64)
+  if (!perm && threadIdx.x < n_off && threadIdx.x < 64)
     lin[threadIdx.x] = (offsets[3 * threadIdx.x] * Y + offsets[3 * threadIdx.x + 1]) * X + offsets[3 * threadIdx.x + 2];
   __syncthreads();
   const unsigned T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -250,9 +253,14 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       if (i < nsurv) e = win[i];
       else {
         const unsigned slot = next + (i - nsurv);
-        const unsigned id = (unsigned)keys[slot];
-        const unsigned k = id / N, u = id - k * N;
-        e = make_uint4(slot, u, (unsigned)((int)u + lin[k]), (k < (unsigned)n_attr ? MWS_ATTR : 0u) | 0x7fffffffu);
+        if (perm) {
+          const unsigned id = perm[slot];
+          e = make_uint4(slot, eu[id], ev[id], (eattr[id] ? MWS_ATTR : 0u) | 0x7fffffffu);
+        } else {
+          const unsigned id = (unsigned)keys[slot];
+          const unsigned k = id / N, u = id - k * N;
+          e = make_uint4(slot, u, (unsigned)((int)u + lin[k]), (k < (unsigned)n_attr ? MWS_ATTR : 0u) | 0x7fffffffu);
+        }
       }
       const int a = mws_find(s.parent, (int)e.y), b = mws_find(s.parent, (int)e.z);
       bool retired = a == b;
@@ -464,7 +472,9 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
-    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul};
+    const unsigned* gperm = nullptr; const unsigned* geu = nullptr; const unsigned* gev = nullptr; const unsigned char* gattr = nullptr;
+    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul,
+                    &gperm, &geu, &gev, &gattr};
     rg_set_kernel_name("mws_rounds_kernel");
     rg_prof_mark(st);
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
@@ -479,6 +489,211 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
   if (rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)q.N, rocprim::plus<unsigned>(), st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: scan failed");
   hipLaunchKernelGGL(mws_label_kernel, dim3(blocks), dim3(256), 0, st, S, mask, (const int*)first, (const unsigned*)rank, (u64*)labels, q.N,
                      (const MwsCtl*)(w + q.off_cnt + 64));
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ==== second level of the slab decomposition: mutex watershed of an explicit edge list ============
+// Nodes are first-level clusters, edges the grid edges that cross a slab boundary plus the mutexes the first level left between
+// clusters of one slab (wkey 0: before everything else).  Order: ascending wkey (= descending transformed weight, the same 32-bit
+// order_desc() value the grid pass ranks by), ties by ascending 64-bit global edge id `gid`.  Same Kruskal rules, same kernel;
+// result: rep[i] = smallest node id of i's cluster.
+__global__ void mws_iota_kernel(unsigned* p, unsigned n) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+}
+__global__ void mws_gather_u32_kernel(const unsigned* src, const unsigned* idx, unsigned* dst, unsigned n) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void mws_rep_kernel(MwsState s, const int* first, int* rep, long N, const MwsCtl* ctl) {
+  const bool bad = ctl->stalled != 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) rep[i] = bad ? -1 : first[s.root[i]];
+}
+struct MwsGraphPlan { long N, E; size_t off_gid2, off_perm, off_perm2, off_wk, off_wk2, off_state, off_pool, off_claim, off_pairs, off_ops, off_win, off_first, off_flags, off_ctl, off_tmp, tmp_bytes, total; long pool_nodes; };
+static int mws_graph_plan(int64_t n_nodes, int64_t n_edges, MwsGraphPlan* q) {
+  if (n_nodes <= 0 || n_nodes >= 0x7fffffffL || n_edges < 0 || n_edges >= 0xffffffffL) return -1;
+  q->N = n_nodes; q->E = n_edges < 1 ? 1 : n_edges;
+  size_t t1 = 0, t2 = 0;
+  rocprim::radix_sort_pairs(nullptr, t1, (u64*)nullptr, (u64*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)q->E, 0, 64, (hipStream_t)0);
+  rocprim::radix_sort_pairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)q->E, 0, 32, (hipStream_t)0);
+  q->tmp_bytes = t1 > t2 ? t1 : t2;
+  q->pool_nodes = 2 * q->E + 2;
+  size_t o = 0;
+  q->off_gid2 = o; o += al((size_t)q->E * 8);
+  q->off_perm = o; o += al((size_t)q->E * 4);
+  q->off_perm2 = o; o += al((size_t)q->E * 4);
+  q->off_wk = o; o += al((size_t)q->E * 4);
+  q->off_wk2 = o; o += al((size_t)q->E * 4);
+  q->off_state = o; o += al((size_t)q->N * 4) * 5;
+  q->off_pool = o; o += al((size_t)q->pool_nodes * 8);
+  q->off_claim = o; o += al((size_t)q->N * 8);
+  q->off_pairs = o; o += al((size_t)8 << MWS_PAIR_BITS);
+  q->off_ops = o; o += al((size_t)MWS_WIN_CAP * 8);
+  q->off_win = o; o += 2 * al((size_t)MWS_WIN_CAP * 16);
+  q->off_first = o; o += al((size_t)q->N * 4);
+  q->off_flags = o; o += al((size_t)q->N * 4);
+  q->off_ctl = o; o += 512;
+  q->off_tmp = o; o += al(q->tmp_bytes);
+  q->total = o;
+  return 0;
+}
+extern "C" int64_t rg_mws_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+  MwsGraphPlan q;
+  if (mws_graph_plan(n_nodes, n_edges, &q)) return -1;
+  return (int64_t)q.total;
+}
+extern "C" int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uint32_t* eu, const uint32_t* ev, const uint8_t* attractive,
+                            int64_t n_edges, int64_t n_nodes, int32_t* rep, void* workspace, size_t ws_bytes, rg_stream s) {
+  MwsGraphPlan q;
+  if (mws_graph_plan(n_nodes, n_edges, &q)) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_graph: bad sizes (nodes %ld, edges %ld)", (long)n_nodes, (long)n_edges);
+  if (!rep || (n_edges > 0 && (!wkey || !gid || !eu || !ev || !attractive))) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_graph: null pointer");
+  if (!workspace || ws_bytes < q.total) RG_FAIL(RG_ERR_WORKSPACE, "mws_graph: workspace %zu < %zu bytes", ws_bytes, q.total);
+  hipStream_t st = (hipStream_t)s;
+  char* w = (char*)workspace;
+  u64* gid2 = (u64*)(w + q.off_gid2);
+  unsigned* perm = (unsigned*)(w + q.off_perm); unsigned* perm2 = (unsigned*)(w + q.off_perm2);
+  unsigned* wk = (unsigned*)(w + q.off_wk); unsigned* wk2 = (unsigned*)(w + q.off_wk2);
+  MwsState S;
+  const size_t nb = al((size_t)q.N * 4);
+  S.parent = (int*)(w + q.off_state); S.root = (int*)(w + q.off_state + nb); S.head = (int*)(w + q.off_state + 2 * nb);
+  S.tail = (int*)(w + q.off_state + 3 * nb); S.cnt = (int*)(w + q.off_state + 4 * nb);
+  S.pool = (int2*)(w + q.off_pool);
+  int* first = (int*)(w + q.off_first); unsigned* flags = (unsigned*)(w + q.off_flags);
+  MwsCtl* ctl = (MwsCtl*)(w + q.off_ctl + 64);
+  unsigned* count = (unsigned*)(w + q.off_ctl);
+  void* tmp = w + q.off_tmp;
+  int blocks = (int)((q.N + 255) / 256); if (blocks > 8192) blocks = 8192;
+  int eblocks = (int)((q.E + 255) / 256); if (eblocks > 8192) eblocks = 8192;
+  if (hipMemsetAsync(w + q.off_ctl, 0, 512, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");
+  hipLaunchKernelGGL(mws_init_kernel, dim3(blocks), dim3(256), 0, st, S, first, flags, q.N);
+  RG_CHECK_LAUNCH();
+  if (n_edges > 0) {
+    // order: stable LSD — by gid, then by wkey
+    hipLaunchKernelGGL(mws_iota_kernel, dim3(eblocks), dim3(256), 0, st, perm, (unsigned)n_edges);
+    RG_CHECK_LAUNCH();
+    size_t tb = q.tmp_bytes;
+    if (rocprim::radix_sort_pairs(tmp, tb, (const u64*)gid, gid2, perm, perm2, (size_t)n_edges, 0, 64, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: sort failed");
+    hipLaunchKernelGGL(mws_gather_u32_kernel, dim3(eblocks), dim3(256), 0, st, wkey, (const unsigned*)perm2, wk, (unsigned)n_edges);
+    RG_CHECK_LAUNCH();
+    tb = q.tmp_bytes;
+    if (rocprim::radix_sort_pairs(tmp, tb, wk, wk2, perm2, perm, (size_t)n_edges, 0, 32, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: sort failed");
+    const unsigned ne = (unsigned)n_edges;
+    if (hipMemcpyAsync(count, &ne, 4, hipMemcpyHostToDevice, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memcpy failed");
+    int wgs = 0;
+    {
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mws_rounds_kernel, MWS_THREADS, 0) != hipSuccess || cus * per_cu < 1)
+        RG_FAIL(RG_ERR_HIP, "mws_graph: cannot size the persistent grid");
+      wgs = cus * per_cu < MWS_MAX_WGS ? cus * per_cu : MWS_MAX_WGS;
+    }
+    const u64* kp = nullptr; const unsigned* cp = count; const int* op = nullptr;
+    u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
+    uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
+    int zz = 1, yy = 1, xx = (int)q.N, no = 0, na = 0;
+    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
+    const unsigned* gperm = perm; const unsigned* geu = eu; const unsigned* gev = ev; const unsigned char* gattr = attractive;
+    if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess ||
+        hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");
+    void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul,
+                    &gperm, &geu, &gev, &gattr};
+    rg_set_kernel_name("mws_rounds_kernel(graph)");
+    if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
+      RG_FAIL(RG_ERR_HIP, "mws_graph: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  hipLaunchKernelGGL(mws_first_kernel, dim3(blocks), dim3(256), 0, st, S, (const unsigned char*)nullptr, first, q.N);
+  RG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mws_rep_kernel, dim3(blocks), dim3(256), 0, st, S, (const int*)first, rep, q.N, (const MwsCtl*)ctl);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
+// ---- building the second-level graph: per-edge passes over a slab's boundary zones (labels are int64 first-level labels) -------
+// Edges (u, v = u + offset k) whose u lies in THIS slab and whose v lies in the neighbour above (dir = +1: offsets with dz > 0)
+// or below (dir = -1: dz < 0).  `nzone` = the neighbour's H boundary planes nearest to this slab (H >= max |dz|), already as
+// GLOBAL cluster ids (0 = masked out).  Validity = the grid pass's rules (in bounds, stride grid in global coordinates for
+// repulsive edges, both ends unmasked).  Records are appended in no particular order (the second level sorts by wkey, gid).
+__global__ void mws_cross_kernel(const float* w, const long* lab, long base_own, const long* nzone, int H, int Zs, int Y, int X, int z0,
+                                 long Ng, int dir, const int* offsets, int n_off, int n_attr, int sz, int sy, int sx, int invert, float bias,
+                                 unsigned* wkey, u64* gid, long* gu, long* gv, unsigned char* attr, unsigned* count, unsigned cap) {
+  const long plane = (long)Y * X, total = (long)n_off * H * plane, Ns = (long)Zs * plane;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % X), y = (int)((t / X) % Y), j = (int)((t / plane) % H), k = (int)(t / (plane * H));
+    const int dz = offsets[3 * k], a = dz < 0 ? -dz : dz;
+    if (dz == 0 || (dz > 0) != (dir > 0) || j >= a || a > Zs) continue;
+    const int zl = dir > 0 ? Zs - a + j : j;                 // u's plane in this slab
+    const int zn = dir > 0 ? j : H + j - a;                  // v's plane in the neighbour zone
+    const int y2 = y + offsets[3 * k + 1], x2 = x + offsets[3 * k + 2];
+    if ((unsigned)y2 >= (unsigned)Y || (unsigned)x2 >= (unsigned)X) continue;
+    if (k >= n_attr && ((z0 + zl) % sz || y % sy || x % sx)) continue;
+    const long ul = (long)zl * plane + (long)y * X + x;
+    const long lu = lab[ul], lv = nzone[(long)zn * plane + (long)y2 * X + x2];
+    if (lu <= 0 || lv <= 0) continue;
+    float ww = w[(long)k * Ns + ul];
+    if (k >= n_attr) { if (invert) ww = __fadd_rn(__fmul_rn(ww, -1.f), 1.f); }
+    else ww = __fadd_rn(ww, bias);
+    const unsigned pos = atomicAdd(count, 1u);
+    if (pos >= cap) continue;
+    wkey[pos] = order_desc(ww);
+    gid[pos] = (u64)k * (u64)Ng + (u64)((long)(z0 + zl) * plane + (long)y * X + x);
+    gu[pos] = base_own + lu; gv[pos] = lv; attr[pos] = k < n_attr ? 1 : 0;
+  }
+}
+// mutexes the first level left between clusters of this slab that both belong to the second-level node set (is_node[label]):
+// every valid repulsive edge inside the slab whose ends carry different labels (see DESIGN.md 6 for why that is the mutex set).
+__global__ void mws_slab_mutex_kernel(const long* lab, const unsigned char* is_node, int Zs, int Y, int X, int z0, const int* offsets, int n_off,
+                                      int n_attr, int sz, int sy, int sx, u64* pairs, unsigned* count, unsigned cap) {
+  const long plane = (long)Y * X, Ns = (long)Zs * plane;
+  for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < Ns; u += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(u % X), y = (int)((u / X) % Y), z = (int)(u / plane);
+    if ((z0 + z) % sz || y % sy || x % sx) continue;
+    const long lu = lab[u];
+    if (lu <= 0 || !is_node[lu]) continue;
+    for (int k = n_attr; k < n_off; ++k) {
+      const int z2 = z + offsets[3 * k], y2 = y + offsets[3 * k + 1], x2 = x + offsets[3 * k + 2];
+      if ((unsigned)z2 >= (unsigned)Zs || (unsigned)y2 >= (unsigned)Y || (unsigned)x2 >= (unsigned)X) continue;
+      const long lv = lab[(long)z2 * plane + (long)y2 * X + x2];
+      if (lv <= 0 || lv == lu || !is_node[lv]) continue;
+      const unsigned pos = atomicAdd(count, 1u);
+      if (pos < cap) pairs[pos] = lu < lv ? ((u64)lu << 32) | (u64)lv : ((u64)lv << 32) | (u64)lu;
+    }
+  }
+}
+__global__ void mws_relabel_kernel(long* labels, const long* lut, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) labels[i] = lut[labels[i]];
+}
+static int mws_slab_args_ok(const rg_mws_params* p) {
+  return p && p->shape[0] > 0 && p->shape[1] > 0 && p->shape[2] > 0 && p->n_offsets > 0 && p->n_offsets <= 64 && p->n_attractive >= 0 &&
+         p->n_attractive <= p->n_offsets && p->strides[0] > 0 && p->strides[1] > 0 && p->strides[2] > 0 && p->origin[0] >= 0;
+}
+extern "C" int rg_mws_cross_edges(const float* weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
+                                  int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
+                                  int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s) {
+  if (!mws_slab_args_ok(p) || !weights || !labels || !nzone || !offsets || !wkey || !gid || !gu || !gv || !attractive || !count || H <= 0 ||
+      (dir != 1 && dir != -1)) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_cross_edges: bad arguments");
+  const long total = (long)p->n_offsets * H * p->shape[1] * p->shape[2];
+  int blocks = (int)((total + 255) / 256); if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(mws_cross_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, weights, (const long*)labels, (long)base_own, (const long*)nzone, H,
+                     p->shape[0], p->shape[1], p->shape[2], p->origin[0], (long)n_global_voxels, dir, offsets, p->n_offsets, p->n_attractive,
+                     p->strides[0], p->strides[1], p->strides[2], p->invert_repulsive_weights, p->bias_cut, wkey, (u64*)gid, (long*)gu, (long*)gv,
+                     attractive, count, cap);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_mws_slab_mutexes(const int64_t* labels, const uint8_t* is_node, const int32_t* offsets, const rg_mws_params* p, uint64_t* pairs,
+                                   uint32_t* count, uint32_t cap, rg_stream s) {
+  if (!mws_slab_args_ok(p) || !labels || !is_node || !offsets || !pairs || !count) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_slab_mutexes: bad arguments");
+  const long Ns = (long)p->shape[0] * p->shape[1] * p->shape[2];
+  int blocks = (int)((Ns + 255) / 256); if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(mws_slab_mutex_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const long*)labels, is_node, p->shape[0], p->shape[1], p->shape[2],
+                     p->origin[0], offsets, p->n_offsets, p->n_attractive, p->strides[0], p->strides[1], p->strides[2], (u64*)pairs, count, cap);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+extern "C" int rg_mws_relabel(int64_t* labels, const int64_t* lut, int64_t n, rg_stream s) {
+  if (!labels || !lut || n < 0) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_relabel: bad arguments");
+  if (n == 0) return RG_OK;
+  int blocks = (int)((n + 255) / 256); if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(mws_relabel_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (long*)labels, (const long*)lut, (long)n);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

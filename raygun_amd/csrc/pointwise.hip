@@ -15,7 +15,11 @@ void rg_set_kernel_name(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_kname, sizeof(g_kname), fmt, ap); va_end(ap);
 }
 extern "C" const char* rg_last_kernel_name(void) { return g_kname; }
-extern "C" int rg_version(void) { return 100; }
+#ifdef RG_STORE_F16
+extern "C" int rg_version(void) { return 101 | (1 << 16); }  // bit 16: this build stores activations / packed weights as IEEE half
+#else
+extern "C" int rg_version(void) { return 101; }
+#endif
 
 // ---- kernel timing aid (bench.py's roofline): HIP events around the DOMINANT kernel of a call, on the launch stream -------
 // A weight-gradient call launches its main kernel plus small reduction passes; timing the whole call from outside would not
@@ -67,8 +71,8 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
   const long nvox = (long)N * D * H * W, total = nvox * G8;
   // the channels-last side (bf16, channel stride 1, 16-byte voxel granules) moves as ONE 16-byte access per thread; the dense
   // side stays one element per lane and channel (consecutive threads = consecutive voxels: coalesced)
-  const bool dst_cl = dst.dtype == RG_BF16 && dst.s[1] == 1 && (lanes & 7) == 0;
-  const bool src_cl = src.dtype == RG_BF16 && src.s[1] == 1 && ((C + 7) / 8 * 8) <= lanes;
+  const bool dst_cl = dst.dtype == RG_ACT_DTYPE && dst.s[1] == 1 && (lanes & 7) == 0;
+  const bool src_cl = src.dtype == RG_ACT_DTYPE && src.s[1] == 1 && ((C + 7) / 8 * 8) <= lanes;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long v = i % nvox; const int grp = (int)(i / nvox);
     long so, dof;
@@ -117,8 +121,8 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
   if (!src || !dst || !src->ptr || !dst->ptr) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: null tensor");
   if (src->rank != 5 || dst->rank != 5) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: rank-5 tensors expected");
   for (int i = 0; i < 5; ++i) if (src->sizes[i] != dst->sizes[i]) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: shape mismatch on dim %d", i);
-  if (dst->dtype != RG_BF16 && dst->dtype != RG_F32) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: dst must be bf16 or f32");
-  if (src->dtype != RG_BF16 && src->dtype != RG_F32 && src->dtype != RG_U8) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: src dtype");
+  if (dst->dtype != RG_ACT_DTYPE && dst->dtype != RG_F32) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: dst must be this build's 16-bit type or f32");
+  if (src->dtype != RG_ACT_DTYPE && src->dtype != RG_F32 && src->dtype != RG_U8) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: src dtype");
   const int C = (int)src->sizes[1];
   if (dst_lanes < C) dst_lanes = C;
   if (dst_lanes > C && dst->strides[1] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: padded lanes need channel stride 1");

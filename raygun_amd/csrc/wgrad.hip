@@ -147,7 +147,7 @@ __global__ __launch_bounds__(WA* WB * 64) void wgrad_kernel(WgradArgs a) {
       for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int j = 0; j < IB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = RG_MFMA16(gf[i], xf[j], acc[i][j]);
     }
   }
 
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
         bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
         bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
         const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[i], 0, 0, 0);
+        acc[i] = RG_MFMA16(gf, xf, acc[i]);
       }
     }
   }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void wgrad_line_kernel(WgradLineArgs p) {
         bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
         bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
         const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc[i], 0, 0, 0);
+        acc[i] = RG_MFMA16(gf, xf, acc[i]);
       }
     }
   };
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SB));
           const bf16x8 xf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int i = 0; i < IA; ++i) acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[tt][i][j], 0, 0, 0);
+          for (int i = 0; i < IA; ++i) acc[tt][i][j] = RG_MFMA16(gf[i], xf, acc[tt][i][j]);
         }
       }
     }
@@ -849,7 +849,7 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + o_hi + j * 16));
           const bf16x8 xf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int i = 0; i < IA; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[t][i][j], 0, 0, 0);
+          for (int i = 0; i < IA; ++i) acc[t][i][j] = RG_MFMA16(gf[i], xf, acc[t][i][j]);
         }
       }
     }

@@ -6,8 +6,9 @@ lanes zero (include/raygun_hip.h).  Crops are zero-copy views.  Anything else ha
 operator (fp32 NCDHW from the user, a dense tensor autograd produced) is converted on the GPU by
 rg_copy_convert.  There is no CPU path: CPU tensors raise.
 """
+import contextlib
 import ctypes as C
-
+import functools
 import os
 import threading
 
@@ -17,7 +18,70 @@ from . import _lib
 from ._lib import ACT, i3, rg_conv_params, rg_pack_params, rg_tensor
 
 _DT = {torch.bfloat16: _lib.RG_BF16, torch.float32: _lib.RG_F32, torch.uint8: _lib.RG_U8,
-       torch.int32: _lib.RG_I32, torch.float64: _lib.RG_F64}
+       torch.int32: _lib.RG_I32, torch.float64: _lib.RG_F64, torch.float16: _lib.RG_F16}
+
+# ---- 16-bit storage type ------------------------------------------------------------------------------------------------------
+# bf16 (default; libraygun_hip.so) or IEEE half (libraygun_hip_f16.so: 11 significant bits — the precision mode of the block
+# runner).  The CURRENT type is thread-local: `with ops.precision("f16"):` sets it for the calling thread, and every
+# autograd Function below runs its forward under the type of its 16-bit inputs (else the current one), remembers it on its ctx
+# and runs its backward — on autograd's own thread — under the same type.
+_KIND = {torch.bfloat16: "bf16", torch.float16: "f16"}
+_HALF = {"bf16": torch.bfloat16, "f16": torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16}
+_prec = threading.local()
+
+
+def storage_dtype():
+    return getattr(_prec, "dtype", torch.bfloat16)
+
+
+@contextlib.contextmanager
+def precision(kind):
+    """Run the enclosed raygun_amd calls with `kind` ("bf16" | "f16" | torch dtype) as the 16-bit storage type."""
+    prev = storage_dtype()
+    _prec.dtype = _HALF[kind]
+    try:
+        yield
+    finally:
+        _prec.dtype = prev
+
+
+def _L():
+    """The library of the current storage type."""
+    return _lib.lib(_KIND[storage_dtype()])
+
+
+def _first_half_dtype(args):
+    for a in args:
+        if torch.is_tensor(a) and a.dtype in _KIND and a.is_cuda:
+            return a.dtype
+    return None
+
+
+class Function(torch.autograd.Function):
+    """torch.autograd.Function whose forward/backward run under one 16-bit storage type (see above)."""
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        fwd, bwd = cls.__dict__.get("forward"), cls.__dict__.get("backward")
+        if fwd is not None:
+            f = fwd.__func__
+
+            @functools.wraps(f)
+            def forward(ctx, *args):
+                dt = _first_half_dtype(args) or storage_dtype()
+                ctx.rg_dtype = dt
+                with precision(dt):
+                    return f(ctx, *args)
+            cls.forward = staticmethod(forward)
+        if bwd is not None:
+            b = bwd.__func__
+
+            @functools.wraps(b)
+            def backward(ctx, *grads):
+                with precision(ctx.rg_dtype):
+                    return b(ctx, *grads)
+            cls.backward = staticmethod(backward)
+
 
 
 def _stream():
@@ -56,7 +120,7 @@ def voxel_stride_of(c):
 
 def cl_empty(n, c, d, h, w, device):
     """Uninitialised channels-last bf16 activation (every kernel writes all lanes incl. zero pad lanes)."""
-    buf = torch.empty((n, d, h, w, voxel_stride_of(c)), dtype=torch.bfloat16, device=device)
+    buf = torch.empty((n, d, h, w, voxel_stride_of(c)), dtype=storage_dtype(), device=device)
     return buf.permute(0, 4, 1, 2, 3)[:, :c]
 
 
@@ -79,7 +143,7 @@ def is_cl_weight(w):
 
 
 def is_cl(t):
-    if t.dtype != torch.bfloat16 or t.dim() != 5 or not t.is_cuda:
+    if t.dtype not in _KIND or t.dim() != 5 or not t.is_cuda:
         return False
     n, c, d, h, w = t.shape
     st = t.stride()
@@ -95,14 +159,14 @@ def to_cl(t, scale=1.0, shift=0.0):
     _require_cuda(t, "to_cl")
     if t.dim() != 5:
         raise RuntimeError(f"raygun_amd: expected a 5-D (N,C,D,H,W) tensor, got shape {tuple(t.shape)}")
-    if scale == 1.0 and shift == 0.0 and is_cl(t):
+    if scale == 1.0 and shift == 0.0 and is_cl(t) and t.dtype == storage_dtype():
         return t
-    if t.dtype not in (torch.bfloat16, torch.float32, torch.uint8):
-        t = t.float()
+    if t.dtype not in (storage_dtype(), torch.float32, torch.uint8):
+        t = t.float()  # (includes a 16-bit tensor of the OTHER storage type: through fp32)
     n, c, d, h, w = t.shape
     out = cl_empty(n, c, d, h, w, t.device)
     if t.numel():
-        _lib.check(_lib.lib().rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), lanes_of(c), scale, shift, _stream()),
+        _lib.check(_L().rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), lanes_of(c), scale, shift, _stream()),
                    "rg_copy_convert")
     return out
 
@@ -114,12 +178,12 @@ def from_cl(t, dtype=torch.float32):
     """channels-last bf16 -> dense NCDHW `dtype` (no autograd)."""
     out = torch.empty(t.shape, dtype=dtype, device=t.device)
     if t.numel():
-        _lib.check(_lib.lib().rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), t.shape[1], 1.0, 0.0, _stream()),
+        _lib.check(_lib.lib(_KIND[t.dtype]).rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), t.shape[1], 1.0, 0.0, _stream()),
                    "rg_copy_convert")
     return out
 
 
-class _ToCL(torch.autograd.Function):
+class _ToCL(Function):
     @staticmethod
     def forward(ctx, x):
         ctx.src_dtype = x.dtype
@@ -130,7 +194,7 @@ class _ToCL(torch.autograd.Function):
         return from_cl(to_cl(g), ctx.src_dtype if ctx.src_dtype.is_floating_point else torch.float32)
 
 
-class _FromCL(torch.autograd.Function):
+class _FromCL(Function):
     @staticmethod
     def forward(ctx, x):
         return from_cl(to_cl(x))
@@ -201,6 +265,8 @@ def invalidate_packed(obj):
 def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     """fp32 torch-layout weight -> packed bf16 [rows16][taps][red32]; cached on the tensor per version."""
     key = (int(swap), tuple(k0), tuple(kstep), None if ntap is None else tuple(ntap))
+    if storage_dtype() != torch.bfloat16:
+        key = key + (_KIND[storage_dtype()],)
     cache = getattr(w, "_rg_pack_cache", None)
     ver = (w._version, w.data_ptr())
     if cache is None or cache.get("ver") != ver:
@@ -224,15 +290,15 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
         p.K[i], p.k0[i], p.kstep[i], p.ntap[i] = K[i], k0[i], kstep[i], nt[i]
     p.swap = int(swap)
     rows, red = (wd.shape[1], wd.shape[0]) if swap else (wd.shape[0], wd.shape[1])
-    p.red_align = _lib.lib().rg_conv3d_kalign(int(red), int(rows))
-    nbytes = _lib.lib().rg_pack_weights_bytes(C.byref(p))
+    p.red_align = _L().rg_conv3d_kalign(int(red), int(rows))
+    nbytes = _L().rg_pack_weights_bytes(C.byref(p))
     if nbytes < 0:
         raise RuntimeError("raygun_amd.pack_weights: bad packing parameters")
-    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
-    _lib.check(_lib.lib().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
+    out = torch.empty(nbytes // 2, dtype=storage_dtype(), device=w.device)
+    _lib.check(_L().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
                "rg_pack_weights")
     cache[key] = out
-    if src_cl and not swap and ntap is None and tuple(k0) == (0, 0, 0) and tuple(kstep) == (1, 1, 1) and red % 4 == 0:
+    if src_cl and not swap and ntap is None and tuple(k0) == (0, 0, 0) and tuple(kstep) == (1, 1, 1) and red % 4 == 0 and len(key) == 4:
         cache["fwd_pack"] = (out, p)  # FusedAdam refreshes this operand in its own pass (adam_step_)
     return out
 
@@ -253,7 +319,7 @@ def profile_start():
     """Start recording a HIP-event pair (on torch's current stream = the launch stream) around every conv kernel."""
     global _prof
     _prof = []
-    L = _lib.lib()
+    L = _lib.lib("bf16")
     L.rg_profile_enable(1)  # weight-gradient calls: event pair around the main kernel only, inside the library
     L.rg_profile_drain(None, 0)
 
@@ -263,7 +329,7 @@ def profile_stop():
     global _prof
     rec, _prof = _prof, None
     torch.cuda.synchronize()
-    L = _lib.lib()
+    L = _lib.lib("bf16")
     L.rg_profile_enable(0)
     marked = [r for r in rec or [] if r[4]]
     buf = (C.c_float * max(1, len(marked)))()
@@ -289,7 +355,7 @@ def _timed(flops, fn, tag=None, marked=False):
     e0.record()
     r = fn()
     e1.record()
-    name = _lib.lib().rg_last_kernel_name().decode()
+    name = _L().rg_last_kernel_name().decode()
     if profile_shapes and tag is not None:
         name += " " + tag()
     _prof.append((name, flops, e0, e1, marked))
@@ -304,7 +370,7 @@ def _igemm(x, wp, bias, y, p):
     bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
     dx, dy = desc(x), desc(y)
     _timed(_conv_flops(p, x.shape[0], x.shape[1], y.shape[1]),
-           lambda: _lib.check(_lib.lib().rg_conv3d_igemm(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
+           lambda: _lib.check(_L().rg_conv3d_igemm(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
                                                          _stream()), "rg_conv3d_igemm"),
            lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} R{tuple(p.R)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)}")
 
@@ -316,12 +382,12 @@ def _wgrad(g, x, p, shape, channels_last=False):
                      memory_format=torch.channels_last_3d if channels_last else torch.contiguous_format)
     ns = C.c_int32(0)
     dg, dx = desc(g), desc(x)
-    nbytes = _lib.lib().rg_conv3d_wgrad_workspace_bytes(C.byref(dg), C.byref(dx), C.byref(p), C.byref(ns))
+    nbytes = _L().rg_conv3d_wgrad_workspace_bytes(C.byref(dg), C.byref(dx), C.byref(p), C.byref(ns))
     if nbytes < 0:
         _lib.check(-1, "rg_conv3d_wgrad_workspace_bytes")
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
     _timed(_conv_flops(p, g.shape[0], x.shape[1], g.shape[1]),
-           lambda: _lib.check(_lib.lib().rg_conv3d_wgrad2(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p),
+           lambda: _lib.check(_L().rg_conv3d_wgrad2(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p),
                                                           2 if channels_last else 0, C.c_void_p(ws.data_ptr()), nbytes, _stream()),
                               "rg_conv3d_wgrad"),
            lambda: f"g{tuple(g.shape)} x{tuple(x.shape)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)} ns{ns.value}", marked=True)
@@ -336,9 +402,9 @@ def _act_bwd_bias(gy, y, act, slope, want_bias):
     g = cl_empty(n, c, d, h, w, gy.device) if act != "none" else None
     db = torch.empty(c, dtype=torch.float32, device=gy.device) if want_bias else None
     dgy = desc(gy)
-    nbytes = _lib.lib().rg_act_bwd_bias_workspace_bytes(C.byref(dgy)) if want_bias else 0
+    nbytes = _L().rg_act_bwd_bias_workspace_bytes(C.byref(dgy)) if want_bias else 0
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
-    _lib.check(_lib.lib().rg_act_bwd_bias(C.byref(dgy), C.byref(desc(y)) if act != "none" else None,
+    _lib.check(_L().rg_act_bwd_bias(C.byref(dgy), C.byref(desc(y)) if act != "none" else None,
                                           C.byref(desc(g)) if g is not None else None,
                                           C.c_void_p(db.data_ptr()) if want_bias else None, ACT[act], float(slope),
                                           C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_act_bwd_bias")
@@ -407,7 +473,7 @@ def _scatter_conv(src, w, bias, out, stride, pad, K, swap, act, slope):
         p = _conv_params(R=(D, H, W), T=(2, 2, 2), rstride=(1, 1, 1), tbase=(0, 0, 0), tstep=(1, 1, 1), ostride=(1, 1, 1),
                          ooffset=(0, 0, 0), cout=8 * out.shape[1], act=act, slope=slope)
         _igemm(src, pack_weights(weff, swap=0), bias.repeat(8) if bias is not None else None, z, p)
-        _lib.check(_lib.lib().rg_d2s_add_act(None, C.byref(desc(z)), C.byref(desc(out)), i3((0, 0, 0)), ACT["none"], 0.0, _stream()),
+        _lib.check(_L().rg_d2s_add_act(None, C.byref(desc(z)), C.byref(desc(out)), i3((0, 0, 0)), ACT["none"], 0.0, _stream()),
                    "rg_d2s_add_act")
         return
     classes = [_parity_classes(size[i], stride[i], pad[i], K[i]) for i in range(3)]
@@ -430,7 +496,7 @@ def _scatter_conv(src, w, bias, out, stride, pad, K, swap, act, slope):
 
 
 # ---------------------------------------------------------------------------------------------- Conv3d
-class _Conv3d(torch.autograd.Function):
+class _Conv3d(Function):
     """torch.nn.Conv3d (+ fused activation), zero padding.  Reference call sites: networks/UNet.py:58-69,
     networks/ResNet.py:283,291-298,337-338,407,416, networks/NLayerDiscriminator.py:136-176."""
 
@@ -573,7 +639,7 @@ def conv3d_linear_pair(x, w_a, b_a, w_b, b_b, padding=0, act="none", slope=0.0):
     return conv3d(z, eye, bc, 1, 0, act, slope)
 
 
-class _ConvTranspose3d(torch.autograd.Function):
+class _ConvTranspose3d(Function):
     """torch.nn.ConvTranspose3d (+ fused activation).  Reference: networks/ResNet.py:325-333, networks/UNet.py:263-269."""
 
     @staticmethod
@@ -619,7 +685,7 @@ def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0
 
 
 # ---------------------------------------------------------------------------------------------- activation
-class _Act(torch.autograd.Function):
+class _Act(Function):
     """Stand-alone activation (when it cannot be fused into a conv / norm epilogue)."""
 
     @staticmethod
@@ -629,7 +695,7 @@ class _Act(torch.autograd.Function):
         y = cl_empty(n, c, d, h, w, x.device)
         # identity "norm" (mean 0, rstd 1) + activation == plain activation: reuse the fused apply kernel
         mr = torch.tensor([0.0, 1.0], dtype=torch.float32, device=x.device).repeat(n * c)
-        _lib.check(_lib.lib().rg_instnorm_apply(C.byref(desc(x)), C.c_void_p(mr.data_ptr()), None, C.byref(desc(y)),
+        _lib.check(_L().rg_instnorm_apply(C.byref(desc(x)), C.c_void_p(mr.data_ptr()), None, C.byref(desc(y)),
                                                 ACT[act], float(slope), _stream()), "rg_instnorm_apply")
         ctx.save_for_backward(y)
         ctx.cfg = (act, slope)
@@ -650,7 +716,7 @@ def activation(x, act, slope=0.0):
 
 
 # ---------------------------------------------------------------------------------------------- max pool
-class _MaxPool3d(torch.autograd.Function):
+class _MaxPool3d(Function):
     """torch.nn.MaxPool3d(k, stride=k) floor mode (MaxDownsample, networks/UNet.py:209-228)."""
 
     @staticmethod
@@ -662,7 +728,7 @@ class _MaxPool3d(torch.autograd.Function):
         if min(O) <= 0:
             raise RuntimeError(f"max_pool3d(): output size too small for input {tuple(x.shape)} and kernel {factor}")
         y = cl_empty(n, c, *O, x.device)
-        _lib.check(_lib.lib().rg_maxpool3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(factor), _stream()), "rg_maxpool3d_fwd")
+        _lib.check(_L().rg_maxpool3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(factor), _stream()), "rg_maxpool3d_fwd")
         ctx.save_for_backward(x)
         ctx.factor = factor
         return y
@@ -673,7 +739,7 @@ class _MaxPool3d(torch.autograd.Function):
         gy = as_cl(gy)
         n, c, D, H, W = x.shape
         gx = cl_empty(n, c, D, H, W, x.device)
-        _lib.check(_lib.lib().rg_maxpool3d_bwd(C.byref(desc(x)), C.byref(desc(gy)), C.byref(desc(gx)), i3(ctx.factor), _stream()),
+        _lib.check(_L().rg_maxpool3d_bwd(C.byref(desc(x)), C.byref(desc(gy)), C.byref(desc(gx)), i3(ctx.factor), _stream()),
                    "rg_maxpool3d_bwd")
         return gx, None
 
@@ -683,7 +749,7 @@ def maxpool3d(x, factor):
 
 
 # ---------------------------------------------------------------------------------------------- upsample+crop+concat
-class _UpCat(torch.autograd.Function):
+class _UpCat(Function):
     """cat([centre_crop(f), centre_crop(nearest_upsample(g))], 1) — Upsample.forward, networks/UNet.py:338-351."""
 
     @staticmethod
@@ -696,7 +762,7 @@ class _UpCat(torch.autograd.Function):
         off_g = [(a - b) // 2 for a, b in zip(up, out_spatial)]
         off_f = [(a - b) // 2 for a, b in zip(f.shape[2:], out_spatial)]
         out = cl_empty(n, cf + cg, *out_spatial, f.device)
-        _lib.check(_lib.lib().rg_upcat_fwd(C.byref(desc(f)), C.byref(desc(g)), C.byref(desc(out)), i3(factor), i3(off_f),
+        _lib.check(_L().rg_upcat_fwd(C.byref(desc(f)), C.byref(desc(g)), C.byref(desc(out)), i3(factor), i3(off_f),
                                            i3(off_g), _stream()), "rg_upcat_fwd")
         ctx.cfg = (factor, off_f, off_g, tuple(f.shape), tuple(g.shape))
         return out
@@ -707,7 +773,7 @@ class _UpCat(torch.autograd.Function):
         go = as_cl(go)
         gf = cl_empty(*fs, go.device)
         gg = cl_empty(*gs, go.device)
-        _lib.check(_lib.lib().rg_upcat_bwd(C.byref(desc(go)), C.byref(desc(gf)), C.byref(desc(gg)), i3(factor), i3(off_f),
+        _lib.check(_L().rg_upcat_bwd(C.byref(desc(go)), C.byref(desc(gf)), C.byref(desc(gg)), i3(factor), i3(off_f),
                                            i3(off_g), _stream()), "rg_upcat_bwd")
         return gf, gg, None, None
 
@@ -716,7 +782,7 @@ def upcat(f, g, factor, out_spatial):
     return _UpCat.apply(f, g, _triple(factor), tuple(int(v) for v in out_spatial))
 
 
-class _SubpixelWeights(torch.autograd.Function):
+class _SubpixelWeights(Function):
     """weight (O, Cf+Cg, 3,3,3) -> (weight[:, :Cf], the (8*O, Cg, 2,2,2) sub-pixel kernels of weight[:, Cf:]) — see
     rg_subpixel_weights: output parity p of a dimension sees taps {0,1 | 2} (p = 0) or {0 | 1,2} (p = 1) fall on low-resolution
     cells s = 0 | 1, so the taps that share a cell are summed; output channel = ((pd*2+ph)*2+pw)*O + o.  Both results are
@@ -730,7 +796,7 @@ class _SubpixelWeights(torch.autograd.Function):
         o, c = w.shape[:2]
         wf = torch.empty((o, cf, 3, 3, 3), dtype=torch.float32, device=w.device, memory_format=torch.channels_last_3d)
         weff = torch.empty((8 * o, c - cf, 2, 2, 2), dtype=torch.float32, device=w.device, memory_format=torch.channels_last_3d)
-        _lib.check(_lib.lib().rg_subpixel_weights(C.byref(desc(w)), cf, C.c_void_p(wf.data_ptr()), C.c_void_p(weff.data_ptr()), _stream()),
+        _lib.check(_L().rg_subpixel_weights(C.byref(desc(w)), cf, C.c_void_p(wf.data_ptr()), C.c_void_p(weff.data_ptr()), _stream()),
                    "rg_subpixel_weights")
         ctx.cfg = (cf, tuple(w.shape), tuple(w.stride()))
         return wf, weff
@@ -742,7 +808,7 @@ class _SubpixelWeights(torch.autograd.Function):
         dw = torch.empty_strided(shape, strides, dtype=torch.float32, device=ref.device)
         cl = lambda t: None if t is None else t.float().contiguous(memory_format=torch.channels_last_3d)  # noqa: E731
         gwf, gweff = cl(gwf), cl(gweff)
-        _lib.check(_lib.lib().rg_subpixel_weights_bwd(C.c_void_p(gwf.data_ptr()) if gwf is not None else None,
+        _lib.check(_L().rg_subpixel_weights_bwd(C.c_void_p(gwf.data_ptr()) if gwf is not None else None,
                                                       C.c_void_p(gweff.data_ptr()) if gweff is not None else None,
                                                       C.byref(desc(dw)), cf, _stream()), "rg_subpixel_weights_bwd")
         return dw, None
@@ -784,14 +850,14 @@ def upcat_conv3d(f, g, target, weight, bias, act="none", slope=0.0):
     return _D2SAddAct.apply(y, z, tuple(ci & 1 for ci in c), act, float(slope))
 
 
-class _D2SAddAct(torch.autograd.Function):
+class _D2SAddAct(Function):
     """act(y + depth_to_space(z)[crop]) in one pass, and its backward in one pass (rg_d2s_add_act / _bwd)."""
 
     @staticmethod
     def forward(ctx, y, z, off, act, slope):
         y, z = as_cl(y), as_cl(z)
         out = cl_empty(*y.shape, y.device)
-        _lib.check(_lib.lib().rg_d2s_add_act(C.byref(desc(y)), C.byref(desc(z)), C.byref(desc(out)), i3(off), ACT[act], slope, _stream()),
+        _lib.check(_L().rg_d2s_add_act(C.byref(desc(y)), C.byref(desc(z)), C.byref(desc(out)), i3(off), ACT[act], slope, _stream()),
                    "rg_d2s_add_act")
         ctx.save_for_backward(out if act != "none" else None)
         ctx.cfg = (off, act, slope, tuple(z.shape))
@@ -804,13 +870,13 @@ class _D2SAddAct(torch.autograd.Function):
         gout = as_cl(gout)
         g = cl_empty(*gout.shape, gout.device)
         gz = cl_empty(*zs, gout.device)
-        _lib.check(_lib.lib().rg_d2s_add_act_bwd(C.byref(desc(gout)), C.byref(desc(out)) if out is not None else None, C.byref(desc(g)),
+        _lib.check(_L().rg_d2s_add_act_bwd(C.byref(desc(gout)), C.byref(desc(out)) if out is not None else None, C.byref(desc(g)),
                                                  C.byref(desc(gz)), i3(off), ACT[act], slope, _stream()), "rg_d2s_add_act_bwd")
         return g, gz, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- instance norm
-class _InstanceNorm(torch.autograd.Function):
+class _InstanceNorm(Function):
     """InstanceNorm3d(affine=False, track_running_stats=False) [+act] [+residual]  (networks/ResNet.py:284-285,
     408-409,417,436-443; NLayerDiscriminator.py:154-156)."""
 
@@ -823,7 +889,7 @@ class _InstanceNorm(torch.autograd.Function):
                 raise RuntimeError("raygun_amd.instance_norm: residual add is fused only without activation")
             res = as_cl(res)
         n, c, d, h, w = x.shape
-        L = _lib.lib()
+        L = _L()
         dx = desc(x)
         nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -845,7 +911,7 @@ class _InstanceNorm(torch.autograd.Function):
         n, c, d, h, w = x.shape
         gx = None
         if ctx.needs_input_grad[0]:
-            L = _lib.lib()
+            L = _L()
             dx = desc(x)
             nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -861,7 +927,7 @@ def instance_norm(x, eps=1e-5, act="none", slope=0.0, residual=None):
 
 
 # ---------------------------------------------------------------------------------------------- padding / add
-class _Pad3d(torch.autograd.Function):
+class _Pad3d(Function):
     """ReflectionPad3d / zero pad (networks/ResNet.py:270,337,392)."""
 
     @staticmethod
@@ -873,7 +939,7 @@ class _Pad3d(torch.autograd.Function):
             raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
                                f"but got: padding {pad} at input {tuple(x.shape)}")
         y = cl_empty(n, c, d + 2 * pad[0], h + 2 * pad[1], w + 2 * pad[2], x.device)
-        _lib.check(_lib.lib().rg_pad3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(pad), mode, _stream()), "rg_pad3d_fwd")
+        _lib.check(_L().rg_pad3d_fwd(C.byref(desc(x)), C.byref(desc(y)), i3(pad), mode, _stream()), "rg_pad3d_fwd")
         ctx.cfg = (pad, mode, tuple(x.shape))
         return y
 
@@ -882,7 +948,7 @@ class _Pad3d(torch.autograd.Function):
         pad, mode, xs = ctx.cfg
         gy = as_cl(gy)
         gx = cl_empty(*xs, gy.device)
-        _lib.check(_lib.lib().rg_pad3d_bwd(C.byref(desc(gy)), C.byref(desc(gx)), i3(pad), mode, _stream()), "rg_pad3d_bwd")
+        _lib.check(_L().rg_pad3d_bwd(C.byref(desc(gy)), C.byref(desc(gx)), i3(pad), mode, _stream()), "rg_pad3d_bwd")
         return gx, None, None
 
 
@@ -890,13 +956,13 @@ def pad3d(x, pad, mode="reflect"):
     return _Pad3d.apply(x, _triple(pad), {"zeros": 0, "reflect": 1}[mode])
 
 
-class _Add(torch.autograd.Function):
+class _Add(Function):
     @staticmethod
     def forward(ctx, a, b):
         _require_cuda(a, "add")
         a, b = as_cl(a), as_cl(b)
         y = cl_empty(*a.shape, a.device)
-        _lib.check(_lib.lib().rg_add(C.byref(desc(a)), C.byref(desc(b)), C.byref(desc(y)), _stream()), "rg_add")
+        _lib.check(_L().rg_add(C.byref(desc(a)), C.byref(desc(b)), C.byref(desc(y)), _stream()), "rg_add")
         return y
 
     @staticmethod
@@ -908,7 +974,7 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
-class _DiagSpread(torch.autograd.Function):
+class _DiagSpread(Function):
     """y[.,h,w][kh*KW+kw] = x[.,h+s*kh,w+s*kw][0] on an (oh, ow) output grid; adjoint: _DiagSum with -s."""
 
     @staticmethod
@@ -917,7 +983,7 @@ class _DiagSpread(torch.autograd.Function):
         x = as_cl(x)
         n, _, d, h, w = x.shape
         y = cl_empty(n, kh * kw, d, oh, ow, x.device)
-        _lib.check(_lib.lib().rg_diag_spread(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign, _stream()), "rg_diag_spread")
+        _lib.check(_L().rg_diag_spread(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign, _stream()), "rg_diag_spread")
         ctx.cfg = (kh, kw, sign, h, w)
         return y
 
@@ -927,7 +993,7 @@ class _DiagSpread(torch.autograd.Function):
         return _DiagSum.apply(g, kh, kw, -sign, h, w, None), None, None, None, None, None
 
 
-class _DiagSum(torch.autograd.Function):
+class _DiagSum(Function):
     """y[.,h,w][0] = bias + sum_{kh,kw} x[.,h+s*kh,w+s*kw][kh*KW+kw] on an (oh, ow) grid; adjoint: _DiagSpread with -s."""
 
     @staticmethod
@@ -937,7 +1003,7 @@ class _DiagSum(torch.autograd.Function):
         n, _, d, h, w = x.shape
         y = cl_empty(n, 1, d, oh, ow, x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        _lib.check(_lib.lib().rg_diag_sum(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign,
+        _lib.check(_L().rg_diag_sum(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign,
                                           C.c_void_p(b.data_ptr()) if b is not None else None, _stream()), "rg_diag_sum")
         ctx.cfg = (kh, kw, sign, h, w, bias is not None)
         return y
@@ -951,7 +1017,7 @@ class _DiagSum(torch.autograd.Function):
         return _DiagSpread.apply(g, kh, kw, -sign, h, w), None, None, None, None, None, gb
 
 
-class _Fork(torch.autograd.Function):
+class _Fork(Function):
     """x -> (x, x) for an activation with two consumers (the U-Net's skip connections): the two gradients are summed by the
     rg_add kernel instead of torch's strided add on padded channels-last views (1.0 ms for 72 x 92^3 on MI355X, 20x slower)."""
 
@@ -965,7 +1031,7 @@ class _Fork(torch.autograd.Function):
             return ga if gb is None else gb
         ga, gb = as_cl(ga), as_cl(gb)
         y = cl_empty(*ga.shape, ga.device)
-        _lib.check(_lib.lib().rg_add(C.byref(desc(ga)), C.byref(desc(gb)), C.byref(desc(y)), _stream()), "rg_add")
+        _lib.check(_L().rg_add(C.byref(desc(ga)), C.byref(desc(gb)), C.byref(desc(y)), _stream()), "rg_add")
         return y
 
 
@@ -973,7 +1039,7 @@ def fork(x):
     return _Fork.apply(x)
 
 
-class _Crop(torch.autograd.Function):
+class _Crop(Function):
     """Zero-copy spatial crop whose backward zero-pads with one rg_add_pad pass, channels-last (torch: NCDHW zeros + strided
     copy, which the next kernel would have to convert back)."""
 
@@ -987,7 +1053,7 @@ class _Crop(torch.autograd.Function):
         shape, off = ctx.cfg
         g = as_cl(g)
         y = cl_empty(*shape, g.device)
-        _lib.check(_lib.lib().rg_add_pad(None, C.byref(desc(g)), C.byref(desc(y)), i3(off), _stream()), "rg_add_pad")
+        _lib.check(_L().rg_add_pad(None, C.byref(desc(g)), C.byref(desc(y)), i3(off), _stream()), "rg_add_pad")
         return y, None, None
 
 
@@ -1008,7 +1074,7 @@ def center_crop(x, shape):
 _LOSS_OUT = 3 + 3 * 512
 
 
-class _Loss(torch.autograd.Function):
+class _Loss(Function):
     """Fused loss value + gradient (losses/GANLoss.py:56-58, LinkCycleLoss.py:99-106, WeightedMSELoss_MTLSD.py:11-25)."""
 
     @staticmethod
@@ -1021,7 +1087,7 @@ class _Loss(torch.autograd.Function):
             raise RuntimeError(f"The size of tensor a ({tuple(pred.shape)}) must match the size of tensor b ({tuple(target.shape)})")
         out = torch.empty(_LOSS_OUT, dtype=torch.float32, device=p.device)
         grad = torch.empty_like(p)
-        _lib.check(_lib.lib().rg_loss_fwd_bwd(kind, C.byref(desc(p)), C.byref(desc(t)) if t is not None else None,
+        _lib.check(_L().rg_loss_fwd_bwd(kind, C.byref(desc(p)), C.byref(desc(t)) if t is not None else None,
                                               C.byref(desc(w)) if w is not None else None, float(const_target), 1.0,
                                               C.byref(desc(grad)), C.c_void_p(out.data_ptr()), _stream()), "rg_loss_fwd_bwd")
         n = p.numel()
@@ -1066,12 +1132,12 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     if cache is not None and cache.get("ver") == (p._version, p.data_ptr()):
         fwd = cache.get("fwd_pack")
     if fwd is not None and os.environ.get("RAYGUN_AMD_ADAM_PACK", "1") != "0":
-        _lib.check(_lib.lib().rg_adam_step_pack(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+        _lib.check(_lib.lib("bf16").rg_adam_step_pack(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                                 C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                                 grad_scale, C.c_void_p(fwd[0].data_ptr()), C.byref(fwd[1]), _stream()),
                    "rg_adam_step_pack")
         return fwd
-    _lib.check(_lib.lib().rg_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+    _lib.check(_lib.lib("bf16").rg_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                        C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                        grad_scale, _stream()), "rg_adam_step")
     return None

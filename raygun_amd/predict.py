@@ -65,7 +65,7 @@ def _to_destination(out, dtype, on_device=False):
 @torch.no_grad()
 def predict_volume(model, source, input_shape=None, output_shape=None, read_size=None, crop=0, ndims=3,
                    scaleShift_input=None, out_dtypes=None, out_channels=None, rank=None, world=None, device=None,
-                   destinations=None):
+                   destinations=None, precision=None):
     """Predict a (Z,Y,X) integer volume block by block.
 
     model: callable taking a (1,1,z,y,x) tensor and returning a tensor or tuple of tensors (worker.py:116-119).
@@ -74,7 +74,19 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
     pipeline there: the destinations are device tensors and nothing crosses PCIe.  Any other array-like with `.shape`,
     `.dtype` and slice reads (a numpy array, a `zarrio.Array`) is read block by block, one block ahead of the GPU; given
     `destinations` (numpy arrays or `zarrio.Array`s) are written in place.  On-disk chunks are only written whole when the
-    dataset's chunk shape equals the write ROI (what `zarrio.prepare_ds(..., write_size=...)` lays down)."""
+    dataset's chunk shape equals the write ROI (what `zarrio.prepare_ds(..., write_size=...)` lays down).
+
+    `precision`: 16-bit storage type of the forward pass, "f16" (default for prediction: IEEE half, 11 significant bits —
+    config U's affinities land within 1e-3 relative L2 of the fp32 reference; same kernel speed) or "bf16" (the
+    training type).  RAYGUN_AMD_PREDICT_PRECISION overrides the default."""
+    precision = precision or os.environ.get("RAYGUN_AMD_PREDICT_PRECISION", "f16")
+    with ops.precision(precision):
+        return _predict_volume(model, source, input_shape, output_shape, read_size, crop, ndims, scaleShift_input, out_dtypes,
+                               out_channels, rank, world, device, destinations)
+
+
+def _predict_volume(model, source, input_shape, output_shape, read_size, crop, ndims, scaleShift_input, out_dtypes, out_channels,
+                    rank, world, device, destinations):
     resident = torch.is_tensor(source) and source.is_cuda
     if resident:
         src_np_dtype = np.dtype(str(source.dtype).replace("torch.", ""))
@@ -160,7 +172,7 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
 
 def predict_zarr(model, source_path, source_dataset, dest_path=None, output_ds=None, out_specs=None, input_shape=None,
                  output_shape=None, read_size=None, crop=0, ndims=3, scaleShift_input=None, out_channels=None, rank=None,
-                 world=None, device=None):
+                 world=None, device=None, precision=None):
     """The on-disk flow of raygun.predict (predict.py:70,111-125,154-164) without daisy / zarr: open the source dataset, lay
     down one destination dataset per model output — same extent, voxel size and offset as the source, chunked by the write
     ROI, dtype from `out_specs[name]["dtype"]` (default: the source's, as the reference does), a channel axis when the output
@@ -187,7 +199,7 @@ def predict_zarr(model, source_path, source_dataset, dest_path=None, output_ds=N
                                "0 prepare them first and pass them to predict_volume)")
         dests = [zarrio.open_ds(dest_path, name, "a") for name in names]
     predict_volume(model, src, input_shape, output_shape, read_size, crop, ndims, scaleShift_input,
-                   [d.dtype for d in dests], out_channels, rank, world, device, destinations=dests)
+                   [d.dtype for d in dests], out_channels, rank, world, device, destinations=dests, precision=precision)
     return dests
 
 

@@ -83,8 +83,8 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
     L = _lib.lib()
     nbytes = L.rg_mws_workspace_bytes(C.byref(p))
     if nbytes < 0:
-        raise RuntimeError("raygun_amd.compute_mws_segmentation: volume too large for one segment "
-                           "(n_offsets * voxels must stay below 2^32) — segment it in blocks (segment_blocks)")
+        raise RuntimeError("raygun_amd.compute_mws_segmentation: volume too large for one pass "
+                           "(n_offsets * voxels must stay below 2^32) — use segment_slabs (Z-slabs + one exchange step)")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(L.rg_mws_segment(C.c_void_p(w.data_ptr()), C.c_void_p(off.data_ptr()),
@@ -120,21 +120,212 @@ def prepare_weights(affs, sep, mask_thresh, max_affinity_value, device=None):
     return w, m
 
 
-def segment_blocks(weights, offsets, sep, strides, mask, block_shape, rank=0, world=1):
-    """Independent mutex watershed per block (no stitching: labels are made unique by a per-block offset).  With
-    world > 1 the blocks are dealt to ranks statically (parallel.shard_blocks) and each rank returns its own blocks'
-    labels, zeros elsewhere: 'replicas only' in SURVEY.md §8e terms."""
-    from .parallel import shard_blocks
-    Z, Y, X = weights.shape[1:]
-    bz, by, bx = block_shape
-    blocks = [(z, y, x) for z in range(0, Z, bz) for y in range(0, Y, by) for x in range(0, X, bx)]
-    out = np.zeros((Z, Y, X), dtype=np.uint64)
-    for bi in shard_blocks(len(blocks), rank, world):
-        z, y, x = blocks[bi]
-        sl = (slice(z, min(z + bz, Z)), slice(y, min(y + by, Y)), slice(x, min(x + bx, X)))
-        seg = compute_mws_segmentation(weights[(slice(None),) + sl], offsets, sep, strides, mask=None if mask is None else mask[sl], origin=(z, y, x))
-        out[sl] = np.where(seg > 0, seg + np.uint64(bi) * np.uint64(bz * by * bx), 0)
-    return out
+def _mws_params(shape, n_off, n_attr, strides, invert, bias, origin):
+    p = rg_mws_params()
+    for i in range(3):
+        p.shape[i], p.strides[i], p.origin[i] = int(shape[i]), 1 if strides is None else int(strides[i]), int(origin[i])
+    p.n_offsets, p.n_attractive, p.randomize_strides = int(n_off), int(n_attr), 0
+    p.invert_repulsive_weights, p.bias_cut = int(bool(invert)), float(bias)
+    return p
+
+
+def slab_bounds(Z, n_slabs, min_thickness=1):
+    """n_slabs Z-slabs of (nearly) equal thickness: [0, b1, ..., Z]."""
+    n_slabs = max(1, min(int(n_slabs), Z // max(1, min_thickness)))
+    return [round(i * Z / n_slabs) for i in range(n_slabs + 1)]
+
+
+def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None, mask=None, n_slabs=None, bounds=None,
+                  invert_repulsive_weights=True, bias_cut=0., device=None, as_tensor=False, z0=0, global_shape=None, group=None):
+    """Mutex watershed of a volume decomposed into Z-slabs, with ONE exchange step: the path past
+    the single-pass limit (n_offsets * voxels < 2^32) and across GPUs (BASELINE config 5).  No reference counterpart — affogato
+    segments one in-memory array; the result is DEFINED by this decomposition and restated on the CPU by oracle.mws.slab_mws
+    (bit-exact test: tests/test_mws.py).  It equals the single-pass result for one slab.
+
+      1. first level: the exact mutex watershed of every slab on its own (rg_mws_segment; stride grid in global coordinates);
+      2. exchange: the H = max|dz| label planes either side of every slab boundary, as global cluster ids;
+      3. second level: a mutex watershed (rg_mws_graph) over the first-level clusters that reach a boundary zone, with the
+         grid edges that cross a boundary (ranked exactly like the first level ranks them) and, ahead of all of them, the
+         mutexes the first level left between such clusters inside a slab.  Clusters outside the zones have no attractive
+         cross edge, can never merge and are left out — exact, not an approximation of the definition;
+      4. relabel: 1 + rank of the cluster's first voxel in global raster order, 0 = masked out (rg_mws_relabel).
+
+    One process, several slabs: pass the whole (n_offsets, Z, Y, X) volume and `n_slabs` / `bounds`.  One slab per rank
+    (torch.distributed initialised, backend nccl = RCCL): pass THIS rank's slab, `z0` = its first global plane and
+    `global_shape`; slabs are ordered by rank.  Step 2 is then a neighbour send/recv, step 3 runs replicated on every rank
+    from an all-gather of the (small) edge records.  Returns this process's labels (uint64 ndarray, or int64 tensor)."""
+    import torch.distributed as dist
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda":
+        raise RuntimeError("raygun_amd.segment_slabs runs on the MI355X only (no CPU fallback)")
+    w = torch.as_tensor(np.ascontiguousarray(weights, dtype=np.float32) if isinstance(weights, np.ndarray) else weights).to(dev, torch.float32).contiguous()
+    off_np = np.ascontiguousarray(offsets, dtype=np.int32)
+    off = torch.as_tensor(off_np).to(dev)
+    K, Zl, Y, X = w.shape
+    n_attr = int(number_of_attractive_channels)
+    m = None
+    if mask is not None:
+        m = torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8) if isinstance(mask, np.ndarray) else mask).to(dev, torch.uint8).contiguous()
+    distributed = global_shape is not None
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    H = max(1, int(np.abs(off_np[:, 0]).max()))
+    if distributed:
+        Zg = int(global_shape[0])
+        mine = [(int(z0), Zl)]
+    else:
+        Zg = Zl
+        if bounds is None:
+            bounds = slab_bounds(Zl, n_slabs or 1, H)
+        mine = [(int(a), int(b - a)) for a, b in zip(bounds[:-1], bounds[1:])]
+    if any(t < H for _, t in mine) and (len(mine) > 1 or distributed):
+        raise ValueError(f"slabs must be at least max|dz| = {H} planes thick")
+    L = _lib.lib()
+    st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
+    # ---- 1. first level
+    labs, counts = [], []
+    for zs, t in mine:
+        zl = zs - (int(z0) if distributed else 0)
+        lab = compute_mws_segmentation(w[:, zl:zl + t], off_np, n_attr, strides, mask=None if m is None else m[zl:zl + t],
+                                       invert_repulsive_weights=invert_repulsive_weights, bias_cut=bias_cut, device=dev,
+                                       as_tensor=True, origin=(zs, 0, 0))
+        if int(lab.view(-1)[0].item()) == -1:
+            raise RuntimeError("raygun_amd.segment_slabs: the device pass made no progress (internal error)")
+        labs.append(lab); counts.append(int(lab.max().item()))
+    if distributed:
+        allc = torch.zeros(world, dtype=torch.int64, device=dev)
+        allc[rank] = counts[0]
+        dist.all_reduce(allc, group=group)
+        all_counts = [int(v) for v in allc.tolist()]
+        my_ids = [rank]
+    else:
+        all_counts, my_ids = counts, list(range(len(mine)))
+    S = len(all_counts)
+    bases = np.concatenate([[0], np.cumsum(all_counts)]).astype(np.int64)
+    if S == 1:
+        out = labs[0]
+        return out if as_tensor else out.cpu().numpy().astype(np.uint64)
+    # ---- 2. boundary zones as global ids
+    def glob(lab, sid):
+        return torch.where(lab > 0, lab + int(bases[sid]), lab)
+    top = {sid: glob(lab[:H], sid).contiguous() for sid, lab in zip(my_ids, labs)}      # first H planes
+    bot = {sid: glob(lab[-H:], sid).contiguous() for sid, lab in zip(my_ids, labs)}     # last H planes
+    if distributed:
+        below = torch.zeros_like(top[rank]); above = torch.zeros_like(top[rank])
+        ops_ = []
+        if rank > 0:
+            ops_ += [dist.P2POp(dist.isend, top[rank], rank - 1, group), dist.P2POp(dist.irecv, below, rank - 1, group)]
+        if rank < world - 1:
+            ops_ += [dist.P2POp(dist.isend, bot[rank], rank + 1, group), dist.P2POp(dist.irecv, above, rank + 1, group)]
+        for r in dist.batch_isend_irecv(ops_) if ops_ else []:
+            r.wait()
+        nb_above = {rank: above}; nb_below = {rank: below}
+    else:
+        nb_above = {sid: top[sid + 1] for sid in my_ids if sid + 1 < S}
+        nb_below = {sid: bot[sid - 1] for sid in my_ids if sid > 0}
+    # ---- 3a. this process's edge records
+    per_dir = {d: int(sum(abs(int(dz)) for dz in off_np[:, 0] if dz * d > 0)) * Y * X for d in (1, -1)}
+    rec = dict(wkey=[], gid=[], gu=[], gv=[], attr=[])
+    mut = []
+    zone_ids = []
+    Ng = Zg * Y * X
+    for sid, lab, (zs, t) in zip(my_ids, labs, mine):
+        zl = zs - (int(z0) if distributed else 0)
+        p = _mws_params((t, Y, X), K, n_attr, strides, invert_repulsive_weights, bias_cut, (zs, 0, 0))
+        wsl = w[:, zl:zl + t].contiguous()
+        for d, nz in ((1, nb_above.get(sid)), (-1, nb_below.get(sid))):
+            if nz is None or per_dir[d] == 0 or (d == 1 and sid == S - 1) or (d == -1 and sid == 0):
+                continue
+            cap = per_dir[d]
+            wk = torch.empty(cap, dtype=torch.int32, device=dev); gid = torch.empty(cap, dtype=torch.int64, device=dev)
+            gu = torch.empty(cap, dtype=torch.int64, device=dev); gv = torch.empty(cap, dtype=torch.int64, device=dev)
+            at = torch.empty(cap, dtype=torch.uint8, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.rg_mws_cross_edges(C.c_void_p(wsl.data_ptr()), C.c_void_p(lab.data_ptr()), int(bases[sid]), C.c_void_p(nz.data_ptr()), H, d, Ng,
+                                                C.c_void_p(off.data_ptr()), C.byref(p), C.c_void_p(wk.data_ptr()), C.c_void_p(gid.data_ptr()),
+                                                C.c_void_p(gu.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(at.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                cap, st()), "rg_mws_cross_edges")
+            n = int(cnt.item())
+            if n > cap:
+                raise RuntimeError("raygun_amd.segment_slabs: cross-edge capacity exceeded (internal error)")
+            for k_, v_ in (("wkey", wk), ("gid", gid), ("gu", gu), ("gv", gv), ("attr", at)):
+                rec[k_].append(v_[:n])
+        # second-level nodes of this slab: clusters with a voxel in a boundary zone
+        zl_ids = torch.unique(torch.cat([lab[:H].reshape(-1) if sid > 0 else lab.new_zeros(0), lab[-H:].reshape(-1) if sid < S - 1 else lab.new_zeros(0)]))
+        zl_ids = zl_ids[zl_ids > 0]
+        zone_ids.append(zl_ids + int(bases[sid]))
+        is_node = torch.zeros(all_counts[sid] + 1, dtype=torch.uint8, device=dev)
+        is_node[zl_ids] = 1
+        nrep = K - n_attr
+        if nrep > 0 and zl_ids.numel() > 1:
+            sz, sy, sx = (1, 1, 1) if strides is None else [int(v) for v in strides]
+            cap = max(1, ((t + sz - 1) // sz + 1) * ((Y + sy - 1) // sy) * ((X + sx - 1) // sx) * nrep)
+            pairs = torch.empty(cap, dtype=torch.int64, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.rg_mws_slab_mutexes(C.c_void_p(lab.data_ptr()), C.c_void_p(is_node.data_ptr()), C.c_void_p(off.data_ptr()), C.byref(p),
+                                                 C.c_void_p(pairs.data_ptr()), C.c_void_p(cnt.data_ptr()), cap, st()), "rg_mws_slab_mutexes")
+            n = int(cnt.item())
+            if n > cap:
+                raise RuntimeError("raygun_amd.segment_slabs: mutex-pair capacity exceeded (internal error)")
+            pr = torch.unique(pairs[:n])
+            mut.append(torch.stack([(pr >> 32) + int(bases[sid]), (pr & 0xffffffff) + int(bases[sid])], 1))
+    cat = lambda xs, dt: torch.cat(xs) if xs else torch.zeros(0, dtype=dt, device=dev)  # noqa: E731
+    wkey, gid, gu, gv, attr = cat(rec["wkey"], torch.int32), cat(rec["gid"], torch.int64), cat(rec["gu"], torch.int64), cat(rec["gv"], torch.int64), cat(rec["attr"], torch.uint8)
+    mutp = torch.cat(mut) if mut else torch.zeros((0, 2), dtype=torch.int64, device=dev)
+    nodes = torch.cat(zone_ids) if zone_ids else torch.zeros(0, dtype=torch.int64, device=dev)
+    if distributed:  # replicate the (small) second-level input on every rank
+        def gather(t):
+            n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n, group=group)
+            mx = max(int(v.item()) for v in ns)
+            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            pad[:t.shape[0]] = t
+            bufs = [torch.zeros_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad, group=group)
+            return torch.cat([b[:int(k.item())] for b, k in zip(bufs, ns)])
+        wkey, gid, gu, gv, attr, mutp, nodes = [gather(t) for t in (wkey, gid, gu, gv, attr, mutp, nodes)]
+    # ---- 3b. second level on compact node indices (sorted global ids: the smallest index is the smallest id)
+    nodes = torch.unique(nodes)
+    n_nodes = int(nodes.numel())
+    rep_g = nodes.clone()
+    if n_nodes > 0 and (wkey.numel() or mutp.numel()):
+        nm = int(mutp.shape[0])
+        eu = torch.searchsorted(nodes, torch.cat([mutp[:, 0], gu])).to(torch.int32)
+        ev = torch.searchsorted(nodes, torch.cat([mutp[:, 1], gv])).to(torch.int32)
+        wk2 = torch.cat([torch.zeros(nm, dtype=torch.int32, device=dev), wkey])
+        gid2 = torch.cat([torch.arange(nm, dtype=torch.int64, device=dev), gid])
+        at2 = torch.cat([torch.zeros(nm, dtype=torch.uint8, device=dev), attr])
+        ne = int(wk2.numel())
+        nbytes = L.rg_mws_graph_workspace_bytes(n_nodes, ne)
+        if nbytes < 0:
+            raise RuntimeError("raygun_amd.segment_slabs: second-level graph too large")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rep = torch.empty(n_nodes, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.rg_mws_graph(C.c_void_p(wk2.data_ptr()), C.c_void_p(gid2.data_ptr()), C.c_void_p(eu.data_ptr()), C.c_void_p(ev.data_ptr()),
+                                      C.c_void_p(at2.data_ptr()), ne, n_nodes, C.c_void_p(rep.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st()),
+                       "rg_mws_graph")
+        if n_nodes and int(rep.min().item()) < 0:
+            raise RuntimeError("raygun_amd.segment_slabs: the second-level pass made no progress (internal error)")
+        rep_g = nodes[rep.long()]
+    nonrep = nodes[rep_g != nodes]                       # sorted: clusters that merged into a smaller id
+    # ---- 4. relabel: final label = rank of the cluster's representative among all representatives
+    outs = []
+    for sid, lab in zip(my_ids, labs):
+        g = torch.arange(all_counts[sid] + 1, dtype=torch.int64, device=dev) + int(bases[sid])
+        r = g.clone()
+        if n_nodes:
+            pos = torch.searchsorted(nodes, g).clamp_(max=n_nodes - 1)
+            hit = nodes[pos] == g
+            r = torch.where(hit, rep_g[pos], g)
+        lut = r - torch.searchsorted(nonrep, r)
+        lut[0] = 0
+        with torch.cuda.device(dev):
+            _lib.check(L.rg_mws_relabel(C.c_void_p(lab.data_ptr()), C.c_void_p(lut.data_ptr()), lab.numel(), st()), "rg_mws_relabel")
+        outs.append(lab)
+    out = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+    return out if as_tensor else out.cpu().numpy().astype(np.uint64)
 
 
 def mutex_segment(config_path, affs=None):
@@ -159,7 +350,12 @@ def mutex_segment(config_path, affs=None):
     if not torch.is_tensor(affs):
         affs = np.asarray(affs, dtype=np.float32)
     weights, mask = prepare_weights(affs, seg_config["sep"], seg_config["mask_thresh"], seg_config["max_affinity_value"])
-    seg = compute_mws_segmentation(weights, neighborhood, seg_config["sep"], strides=[10, 10, 10], mask=mask)
+    n_vox = int(np.prod(weights.shape[1:]))
+    n_slabs = seg_config.get("n_slabs") or -(-(n_vox * weights.shape[0]) // (2 ** 32 - 2 ** 24))   # one pass holds n_offsets * voxels < 2^32 edge ids
+    if n_slabs > 1:   # beyond one pass (or on request): Z-slabs + one exchange step; the result is defined by that decomposition
+        seg = segment_slabs(weights, neighborhood, seg_config["sep"], strides=[10, 10, 10], mask=mask, n_slabs=n_slabs)
+    else:
+        seg = compute_mws_segmentation(weights, neighborhood, seg_config["sep"], strides=[10, 10, 10], mask=mask)
     if ("save" in seg_config and not seg_config["save"]) or f is None:
         return seg
     dest = seg_config.get("dest_dataset", f"mutex_{'{:.2f}'.format(seg_config['mask_thresh'])}")

@@ -22,7 +22,8 @@ from ...load_system import load_system
 from ...read_config import read_config
 
 RENDER_DEFAULTS = {"crop": 0, "read_size": None, "max_retries": 2, "num_workers": 16, "ndims": None, "net_name": None,
-                   "scaleShift_input": None, "output_ds": None, "out_specs": None}
+                   "scaleShift_input": None, "output_ds": None, "out_specs": None,
+                   "precision": None}  # build-owned key: "f16" (default) | "bf16" storage of the forward pass (predict.predict_volume)
 
 
 def read_render_config(render_config_path):
@@ -87,7 +88,7 @@ def worker(render_config_path, rank=None, world=None, device=None):
     shapes = shape_args(render_config, train_config)
     dests, n = predict_volume(model, source, ndims=render_config["ndims"], scaleShift_input=render_config["scaleShift_input"],
                               out_dtypes=[d.dtype for d in destinations], rank=rank, world=world, device=device,
-                              destinations=destinations, **shapes)
+                              destinations=destinations, precision=render_config["precision"], **shapes)
     logger.info(f"Wrote {n} blocks to {', '.join(output_ds)}.")
     return dests, n
 

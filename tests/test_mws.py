@@ -131,3 +131,49 @@ def test_gpu_ties_and_empty():
         compute_mws_segmentation(w, NB8, 3, algorithm="prim")
     with pytest.raises(ValueError):
         compute_mws_segmentation(w[:5], NB8, 3)
+
+
+def test_slab_oracle_reduces_to_single_pass():
+    """oracle.slab_mws (the CPU restatement of the two-level slab decomposition) with ONE slab is the plain
+    mutex watershed; with several slabs it is a different, decomposition-defined partition."""
+    w = synth.uniform((8, 12, 10, 9), 3, 0, 1)
+    m = synth.uniform((12, 10, 9), 4, 0, 1) > 0.15
+    one = O.compute_mws_segmentation(w, NB8, 3, (2, 2, 2), m)
+    assert np.array_equal(O.slab_mws(w, NB8, 3, (2, 2, 2), m, [0, 12]), one)
+    two = O.slab_mws(w, NB8, 3, (2, 2, 2), m, [0, 6, 12])
+    assert np.array_equal(two == 0, one == 0) and two.max() > 1
+    # the graph oracle on a hand-made case: a-b attract strongly, b-c attract weakly but a|c repel in between
+    rep = O.graph_mws(3, [10, 30, 20], [0, 1, 2], [0, 1, 0], [1, 2, 2], [1, 1, 0])
+    assert rep.tolist() == [0, 0, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,strides,bounds,use_mask", [
+    ((48, 40, 44), (2, 2, 2), [0, 24, 48], True), ((48, 40, 44), (2, 2, 2), [0, 10, 31, 48], False),
+    ((40, 36, 36), (1, 1, 1), [0, 20, 40], True), ((64, 48, 48), (4, 4, 4), [0, 16, 32, 48, 64], True)])
+def test_gpu_slab_decomposition_bit_exact(shape, strides, bounds, use_mask):
+    """segment_slabs (first level per slab, boundary-zone exchange, second-level mutex watershed over the clusters that reach
+    a zone, global relabel — all on the GPU) against oracle.slab_mws, which runs the second level over ALL clusters and ALL
+    intra-slab mutexes: bit-exact, so the GPU path's node filter is exact too."""
+    from raygun_amd.segment import compute_mws_segmentation, segment_slabs
+    w = (0.7 * blobs(shape, 2)[None] + 0.3 * synth.uniform((8,) + shape, 11, 0, 1)).astype(np.float32)
+    mask = (synth.uniform(shape, 12, 0, 1) > 0.2) if use_mask else None
+    ref = O.slab_mws(w, NB8, 3, strides, mask, bounds)
+    got = segment_slabs(w, NB8, 3, strides, mask=mask, bounds=bounds)
+    assert got.dtype == np.uint64 and (got == ref).all(), f"{int((got != ref).sum())} of {ref.size} labels differ"
+    # one slab == the single pass
+    assert (segment_slabs(w, NB8, 3, strides, mask=mask, n_slabs=1) == compute_mws_segmentation(w, NB8, 3, strides, mask=mask)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_mutex_segment_in_slabs_reference_pipeline():
+    """mutex_segment with "n_slabs": 2 (what volumes beyond the single-pass limit get automatically): the reference's 20-offset /
+    sep 3 / stride 10 / masked pipeline on a 96^3 volume in 2 slabs against the oracle with the identical decomposition."""
+    from raygun_amd.segment import mutex_segment, slab_bounds
+    shape = (96, 96, 96)
+    affs = (0.75 * blobs(shape, 1)[None] + 0.25 * synth.uniform((20,) + shape, 21, 0, 1)).astype(np.float32)
+    seg = mutex_segment({"mutex": True, "save": False, "n_slabs": 2}, affs=affs.copy())
+    ww, m = O.prepare(affs.copy())
+    assert slab_bounds(96, 2, 8) == [0, 48, 96]
+    ref = O.slab_mws(ww, O.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m, [0, 48, 96])
+    assert (seg == ref).all() and seg.max() > 1 and (seg[~m] == 0).all()

@@ -224,3 +224,46 @@ def test_mtlsd_196_sampled():
         g = P[k].grad.double()
         assert abs(float(g.sum()) - s1) <= 0.08 * sabs, (k, float(g.sum()), s1, sabs)
         assert abs(float(g.abs().sum()) - sabs) <= 0.15 * sabs, (k, float(g.abs().sum()), sabs)
+
+
+@pytest.mark.parametrize("size,name", [(100, "mtlsd_100"), (196, "mtlsd_196_sampled")])
+def test_mtlsd_f16_storage_within_1e3_of_reference(size, name):
+    """north_star: "affinities within 1e-3 rel of reference".  With IEEE-half storage (ops.precision("f16"): the same kernels
+    built with v_mfma_f32_16x16x32_f16, libraygun_hip_f16.so) config U's affinities + LSDs are within 1e-3 relative L2 of the
+    reference's fp32 CPU outputs at both fixture sizes (measured 8.2e-4 / 8.8e-4; bf16 storage: 6.6e-3 — one bf16 rounding is
+    already 2-4e-3).  This is the block runner's default precision (predict.predict_volume)."""
+    from raygun_amd import ops
+    from raygun_amd.torch.models import MTLSDModel
+    fx = np.load(os.path.join(G, name + ".npz"))
+    dev = torch.device("cuda")
+    m = MTLSDModel()
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 51))
+    m = m.to(dev).eval()
+    raw = T(synth.uniform((1, 1, size, size, size), 52)).to(dev)
+    with torch.no_grad(), ops.precision("f16"):
+        affs, lsds = m(raw)
+    assert affs.dtype == torch.float32 and lsds.dtype == torch.float32
+    if size == 100:
+        assert l2rel(affs, fx["affs"]) <= 1e-3 and l2rel(lsds, fx["lsds"]) <= 1e-3
+        assert float(np.abs(affs.cpu().numpy() - fx["affs"]).max()) <= 5e-3
+    else:
+        flat = torch.cat([affs.reshape(-1), lsds.reshape(-1)])
+        got = flat[torch.from_numpy(fx["out_idx"]).to(dev)].cpu().numpy()
+        assert l2rel(got, fx["out_val"]) <= 1e-3 and float(np.abs(got - fx["out_val"]).max()) <= 5e-3
+        sums = np.array([float(affs.double().sum()), float(lsds.double().sum())])
+        assert np.all(np.abs(sums - fx["out_sum"]) <= 2e-4 * np.abs(fx["out_sum"]))
+
+
+def test_f16_storage_training_step_small_unet():
+    """The f16 build carries every kernel (dgrad, wgrad, pointwise), so a train step runs under ops.precision("f16") too:
+    gradients of a smooth small U-Net against the reference fixture, tighter than the bf16 policy's 4e-2."""
+    from raygun_amd import ops
+    mod, fx = build("unet_smooth")
+    with ops.precision("f16"):
+        mod, x, ys, gs = run_fixture(mod, fx, torch.device("cuda"))
+    assert l2rel(ys[0], fx["y0"]) <= 3e-3
+    assert l2rel(x.grad, fx["gx"]) <= 8e-3
+    params = dict(mod.named_parameters())
+    for k in fx.files:
+        if k.startswith("gw::") and np.abs(fx[k]).max() >= 1e-3:
+            assert l2rel(params[k[4:]].grad, fx[k]) <= 8e-3, k

@@ -104,8 +104,10 @@ def test_predict_real_geometry_196_to_104_vs_cpu_oracle():
     """Config 5's predict half at the REAL block geometry: MTLSDModel(num_affs=20) (config U, 259 M parameters), read ROI
     196^3 -> write ROI 104^3, context 46, a 300^3 uint8 volume = 2 x 2 x 2 blocks (worker.py:94-160 per block).  Oracle:
     oracle.torch_ref.MTLSDModel (fp32, CPU, pinned to the reference by tests/golden/mtlsd_*.npz) run with the identical block
-    decomposition and the worker's arithmetic ((x - min)/max, *2-1, centre crop, float32 destination).  Tolerance: the bf16
-    storage policy of DESIGN 4 (post-sigmoid values in (0,1))."""
+    decomposition and the worker's arithmetic ((x - min)/max, *2-1, centre crop, float32 destination).  The block runner stores
+    activations as IEEE half by default: every block must lie within 1.5e-3 relative L2 / 6e-3 absolute of the fp32
+    reference (post-sigmoid values in (0,1); north_star: "affinities within 1e-3 rel", measured 0.8-0.9e-3 on the fixtures);
+    the same volume predicted with bf16 storage is held to that policy's 1.5e-2 / 4e-2."""
     from oracle import torch_ref as O
     from raygun_amd.torch.models import MTLSDModel
     dev = torch.device("cuda")
@@ -117,6 +119,8 @@ def test_predict_real_geometry_196_to_104_vs_cpu_oracle():
     dests, n = P.predict_volume(m, vol, input_shape=196, output_shape=104, scaleShift_input=[2, -1],
                                 out_dtypes=[np.float32, np.float32])
     assert n == 8 and dests[0].shape == (20, 300, 300, 300) and dests[1].shape == (10, 300, 300, 300)
+    bdests, _ = P.predict_volume(m, vol[:196], input_shape=196, output_shape=104, scaleShift_input=[2, -1],
+                                 out_dtypes=[np.float32, np.float32], precision="bf16")   # first 4 blocks, training precision
     read, write, ctx = P.roi_geometry(3, 196, 104)
     blocks = P.enumerate_blocks(vol.shape, read, write, ctx)
     assert blocks == [(z, y, x) for z in (46, 150) for y in (46, 150) for x in (46, 150)]
@@ -127,11 +131,14 @@ def test_predict_real_geometry_196_to_104_vs_cpu_oracle():
             data = torch.from_numpy(vol[wz - 46:wz + 150, wy - 46:wy + 150, wx - 46:wx + 150].astype(np.float32))[None, None]
             data = (data - 0.0) / 255.0 * 2 - 1
             affs, lsds = ref(data)
-            for got, want in ((dests[0], affs[0].numpy()), (dests[1], lsds[0].numpy())):
+            for got, bgot, want in ((dests[0], bdests[0], affs[0].numpy()), (dests[1], bdests[1], lsds[0].numpy())):
                 g = got[:, wz:wz + 104, wy:wy + 104, wx:wx + 104]
                 err = float(np.abs(g - want).max())
                 worst = max(worst, err)
-                assert err <= 4e-2, (wz, wy, wx, err)
-                assert np.sqrt(((g - want) ** 2).sum() / (want ** 2).sum()) <= 1.5e-2
+                assert err <= 6e-3, (wz, wy, wx, err)
+                assert np.sqrt(((g - want) ** 2).sum() / (want ** 2).sum()) <= 1.5e-3
+                if wz == 46:
+                    b = bgot[:, wz:wz + 104, wy:wy + 104, wx:wx + 104]
+                    assert float(np.abs(b - want).max()) <= 4e-2 and np.sqrt(((b - want) ** 2).sum() / (want ** 2).sum()) <= 1.5e-2
     assert (dests[0][:, :46] == 0).all() and (dests[0][:, 254:] == 0).all()  # nothing written outside the write ROIs
     print(f"predict 196->104 x 8 blocks: worst |diff| vs fp32 CPU oracle {worst:.2e}")

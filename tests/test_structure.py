@@ -21,7 +21,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/raygun_hip.h but not exported"
     assert declared == set(_lib.DECLARED), declared ^ set(_lib.DECLARED)
-    assert lib.rg_version() >= 100
+    assert lib.rg_version() >= 100 and not lib.rg_version() >> 16
+    # the IEEE-half build of the same sources: every entry point except the mutex watershed (no 16-bit data on that path)
+    half = _lib.lib("f16")
+    for name in declared - _lib._F16_ABSENT:
+        assert hasattr(half, name), f"{name} missing from libraygun_hip_f16.so"
+    assert half.rg_version() >> 16 == 1
 
 
 def test_mtlsd_structure_matches_reference():
