@@ -324,6 +324,61 @@ __global__ void act_bwd_bias_kernel(CL5 gy, CL5 y, CL5 g, float* partial, int ac
     for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * gy.lanes + grp * 8 + k] = sum[k];
   }
 }
+// Dense fast path: gy, y and g are whole channels-last buffers with one voxel stride (no crops), so the tensor is a flat array of
+// 16-byte pieces, piece i = (voxel i / S8, channel group i % S8), S8 = voxel stride / 8.  A thread's stride through the array is a
+// multiple of S8: its channel group never changes (no per-piece division), pieces of pad groups (>= G8) are skipped by the
+// threads that own them, and four pieces are in flight per thread.  partial[blockIdx.x][lanes] as in the general kernel.
+__global__ __launch_bounds__(256) void act_bwd_bias_dense_kernel(const bf16_t* gy, const bf16_t* y, bf16_t* g, float* partial, long npieces, int S8,
+                                                                int G8, int lanes, int act, float slope, int has_y, long step) {
+  __shared__ float red[256 * 8];
+  const long t0 = (long)blockIdx.x * 256 + threadIdx.x;   // (gridDim.x * 256) % S8 == 0 and 256 % S8 == 0 or handled by `step`
+  const int grp = (int)(t0 % S8);
+  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (grp < G8) {
+    for (long i = t0; i < npieces; i += 4 * step) {
+      bf16x8 a[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long j = i + u * step;
+        if (j < npieces) { a[u] = *(const bf16x8*)(gy + j * 8); if (has_y) yy[u] = *(const bf16x8*)(y + j * 8); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long j = i + u * step;
+        if (j >= npieces) break;
+        bf16x8 o = a[u];
+        if (has_y) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float gv = bf2f((bf16_t)a[u][k]) * act_bwd_from_y(bf2f((bf16_t)yy[u][k]), act, slope);
+            const bf16_t r = f2bf(gv); o[k] = (short)r; sum[k] += bf2f(r);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sum[k] += bf2f((bf16_t)a[u][k]);
+        }
+        if (g) *(bf16x8*)(g + j * 8) = o;
+      }
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sum[k];
+  __syncthreads();
+  // threads of one workgroup with equal (threadIdx.x % S8) share a channel group: thread grp < S8 sums them in a fixed order
+  if ((int)threadIdx.x < S8 && (int)threadIdx.x < G8) {
+    const int first = (int)(((long)threadIdx.x - (long)blockIdx.x * 256 % S8 + S8) % S8);  // smallest thread index of this block whose group == threadIdx.x
+    float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = first; t < 256; t += S8)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tot[k] += red[t * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[(long)blockIdx.x * lanes + threadIdx.x * 8 + k] = tot[k];
+  }
+}
+static bool abb_dense(const CL5& t) {  // one voxel stride for the whole buffer, no gaps between lines / planes / samples
+  return t.sh == (long)t.W * t.sw && t.sd == (long)t.H * t.sh && (t.N == 1 || t.sn == (long)t.D * t.sd) && t.sw % 8 == 0 && t.sw / 8 <= 256;
+}
 // out[c] = sum_b partial[b][c]: one workgroup per channel, fixed-order tree (deterministic)
 __global__ void reduce_partials_kernel(const float* partial, float* out, int nblk, int lanes, int C) {
   __shared__ float red[256];
@@ -367,6 +422,32 @@ extern "C" int rg_act_bwd_bias(const rg_tensor* gy, const rg_tensor* y, const rg
     const size_t need = (size_t)nblk * GY.lanes * 4;
     if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "act_bwd: workspace %zu < %zu", ws_bytes, need);
     partial = (float*)workspace;
+  }
+  const bool has_g = g && g->ptr;
+  if (abb_dense(GY) && (!has_y || (abb_dense(Y) && Y.sw == GY.sw)) && (!has_g || (abb_dense(G) && G.sw == GY.sw))) {
+    const int S8 = (int)(GY.sw / 8), G8 = GY.lanes / 8;
+    const long npieces = (long)GY.N * GY.D * GY.H * GY.W * S8;
+    // grid: at most nblk workgroups (the workspace holds nblk partial rows); total threads a multiple of S8
+    long blocks = (npieces + 256 * 4 - 1) / (256 * 4); if (blocks > nblk) blocks = nblk; if (blocks < 1) blocks = 1;
+    long step = blocks * 256; step = (step + S8 - 1) / S8 * S8;    // >= the thread count: some pieces are then visited by nobody? no: see below
+    // step must EQUAL the thread count for full coverage; make the thread count a multiple of S8 instead: 256 * blocks is one iff
+    // blocks % (S8 / gcd(256, S8)) == 0 — round blocks down to such a count (S8 <= 256)
+    int gcd = 256, b2 = S8; while (b2) { const int t2 = gcd % b2; gcd = b2; b2 = t2; }
+    const long q = S8 / gcd;
+    if (blocks >= q) blocks = blocks / q * q; else blocks = q <= nblk ? q : 0;
+    if (blocks > 0) {
+      step = blocks * 256;
+      if (partial && blocks < nblk && hipMemsetAsync(partial + blocks * GY.lanes, 0, (size_t)(nblk - blocks) * GY.lanes * 4, (hipStream_t)s) != hipSuccess)
+        RG_FAIL(RG_ERR_HIP, "act_bwd: memset failed");
+      hipLaunchKernelGGL(act_bwd_bias_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)GY.p, has_y ? (const bf16_t*)Y.p : nullptr,
+                         has_g ? G.p : nullptr, partial, npieces, S8, G8, GY.lanes, act, slope, has_y, step);
+      RG_CHECK_LAUNCH();
+      if (db) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(GY.C), dim3(256), 0, (hipStream_t)s, partial, db, nblk, GY.lanes, GY.C);
+        RG_CHECK_LAUNCH();
+      }
+      return RG_OK;
+    }
   }
   dim3 grid(nblk, (GY.lanes / 8 + gx - 1) / gx), block(gx, gyy);
   hipLaunchKernelGGL(act_bwd_bias_kernel, grid, block, 256 * 8 * sizeof(float), (hipStream_t)s, GY, Y, G, partial, act, slope, vpb, has_y);

@@ -931,7 +931,10 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   if (const int kind = wgrad_kw_kind(G, X, p, *fa, *fb, &kg)) {  // wgrad_kw_kernel: split over 32-row units
     const long units = kg.units;
     const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
-    const long target = kind == 3 ? 768 : 1536;  // workgroups aimed at (measured per tile shape)
+    // workgroups aimed at: three rounds of one workgroup per CU.  Measured on the U-Net step (whole step, so the partial-sum
+    // traffic and the reduction passes behind the kernel count): 1536 -> 29.96 ms, 1024 -> 29.68, 768 -> 29.37, 512 -> 29.46, 384 -> 30.55
+    (void)kind;
+    const long target = 768;
     // the targets are whole rounds of co-resident workgroups: round the split count DOWN so that the grid never spills a few
     // workgroups into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815)
     long ns = target / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
@@ -976,7 +979,7 @@ extern "C" int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   if (nsplit_out) *nsplit_out = ns;
   const int64_t total = (int64_t)G.C * X.C * p->T[0] * p->T[1] * p->T[2];
-  return (ns + (ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;
+  return (ns + (ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;  // (an upper bound of what rg_conv3d_wgrad2 uses)
 }
 
 template <int FA, int FB, int WA, int WB>
@@ -1008,6 +1011,35 @@ __global__ void wgrad_sum_kernel(const float* part, float* out, long total, int 
   for (int s = 0; s < nsplit; ++s) v += part[s * total + i];
   out[i] = v;
 }
+// The same sum, four elements per thread and four splits per workgroup row: block = 64 element lanes x 4 split lanes, every
+// thread keeps up to four 16-byte loads in flight; split lane y sums splits y, y+4, ... in order, lane 0 then adds the four
+// partial sums in order — a fixed association, deterministic like every reduction here.  One pass for up to 64 splits.
+__global__ __launch_bounds__(256) void wgrad_sum4_kernel(const float4* part, float4* out, long total4, int nsplit, int accumulate) {
+  __shared__ float4 red[3][64];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lx;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total4) {
+    int sp = ly;
+    for (; sp + 12 < nsplit; sp += 16) {
+      const float4 a = part[(long)sp * total4 + i], b = part[(long)(sp + 4) * total4 + i], c = part[(long)(sp + 8) * total4 + i],
+                   d = part[(long)(sp + 12) * total4 + i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+      v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    }
+    for (; sp < nsplit; sp += 4) { const float4 a = part[(long)sp * total4 + i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+  }
+  if (ly) red[ly - 1][lx] = v;
+  __syncthreads();
+  if (ly == 0 && i < total4) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float4 a = red[k][lx]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    if (accumulate) { const float4 o = out[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    out[i] = v;
+  }
+}
 extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* dw, const rg_conv_params* p, int flags,
                                 void* workspace, size_t ws_bytes, rg_stream s) {
   const int accumulate = flags & 1, dw_cl = (flags >> 1) & 1;
@@ -1018,7 +1050,10 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   const size_t total_el = (size_t)G.C * X.C * ntaps;
-  const int nfold = ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0;  // serial split loops in the finish are latency-bound
+  // channels-last dw with a multiple of four elements: one vectorised pass sums up to 64 splits (wgrad_sum4_kernel); otherwise,
+  // and for the thin layers' hundreds of splits, fold groups of 16 first (serial split loops in the finish are latency-bound)
+  const bool sum4 = dw_cl && (total_el & 3) == 0 && (((uintptr_t)dw | (uintptr_t)workspace) & 15) == 0;
+  const int nfold = (sum4 ? ns > 64 : ns > 8) ? (ns + WF_FOLD - 1) / WF_FOLD : 0;
   const size_t need = (size_t)(ns + nfold) * total_el * 4;
   if (!workspace || ws_bytes < need) RG_FAIL(RG_ERR_WORKSPACE, "wgrad: workspace %zu < %zu bytes", ws_bytes, need);
   if (!dw) RG_FAIL(RG_ERR_BAD_SHAPE, "wgrad: null dw");
@@ -1102,7 +1137,8 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     RG_CHECK_LAUNCH();
     fin = folded; nfin = nfold;
   }
-  if (dw_cl) hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((total_el + 255) / 256)), dim3(256), 0, st, fin, dw, (long)total_el, nfin, accumulate);
+  if (sum4) hipLaunchKernelGGL(wgrad_sum4_kernel, dim3((unsigned)((total_el / 4 + 63) / 64)), dim3(256), 0, st, (const float4*)fin, (float4*)dw, (long)(total_el / 4), nfin, accumulate);
+  else if (dw_cl) hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((total_el + 255) / 256)), dim3(256), 0, st, fin, dw, (long)total_el, nfin, accumulate);
   else hipLaunchKernelGGL(wgrad_finish_kernel, dim3(G.C * ((X.C + 63) / 64)), dim3(256), 0, st, fin, dw, G.C, X.C, ntaps, nfin, accumulate);
   RG_CHECK_LAUNCH();
   return RG_OK;

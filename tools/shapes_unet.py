@@ -14,7 +14,7 @@ ops.profile_start()
 for _ in range(5): step(sync)
 prof = ops.profile_stop()
 tot = 0
-for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:28]:
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:80]:
     ms = v["ms"] / 5; tot += ms
     print(f"{ms:7.3f} ms {v['flops']/5/1e12:6.3f} TF {v['flops']/(v['ms']*1e-3)/1e12:7.1f} TF/s  x{v['launches']//5}  {k}")
 print("sum", tot)
