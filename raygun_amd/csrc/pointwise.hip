@@ -211,17 +211,31 @@ __global__ __launch_bounds__(256) void pack_cl_rows_kernel(const float* w, bf16_
   }
 }
 __global__ __launch_bounds__(256) void pack_cl_transpose_kernel(const float* w, bf16_t* out, rg_pack_params p, int rows, int red, int rows16, int red32, long rowlen) {
-  __shared__ float tile[64][65];  // [k (dim0)][r (dim1)]
+  __shared__ __attribute__((aligned(16))) float tile[64][68];  // [k (dim0)][r (dim1)], rows 16-byte aligned for the float4 stores
   const int ntap = p.ntap[0] * p.ntap[1] * p.ntap[2], kvol = p.K[0] * p.K[1] * p.K[2];
   const int nkt = (red32 + 63) / 64, nrt = (rows16 + 63) / 64;
+  (void)ntap;
   int b = blockIdx.x;
   const int kt = b % nkt; b /= nkt; const int rt = b % nrt; const int tap = b / nrt;
   const int k0 = kt * 64, r0 = rt * 64, st = pk_src_tap(p, tap);
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int kk = i >> 6, rr = i & 63;
-    float v = 0.f;
-    if (k0 + kk < red && r0 + rr < rows) v = w[((long)(k0 + kk) * kvol + st) * p.dim1 + r0 + rr];
-    tile[kk][rr] = v;
+  const bool v4 = (p.dim1 & 3) == 0 && ((uintptr_t)w & 15) == 0;  // source rows (dim1 floats) keep 16-byte alignment
+  if (v4) {
+#pragma unroll
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {   // four 16-byte loads per thread in flight
+      const int kk = i >> 4, rr = (i & 15) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + kk < red && r0 + rr < rows) {            // rows % 4 == 0: a piece is wholly inside or outside
+        v = *(const float4*)(w + ((long)(k0 + kk) * kvol + st) * p.dim1 + r0 + rr);
+      }
+      *(float4*)&tile[kk][rr] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int kk = i >> 6, rr = i & 63;
+      float v = 0.f;
+      if (k0 + kk < red && r0 + rr < rows) v = w[((long)(k0 + kk) * kvol + st) * p.dim1 + r0 + rr];
+      tile[kk][rr] = v;
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 8; i += 256) {
@@ -977,29 +991,36 @@ __device__ __forceinline__ void adam_one(float& pi, float gi, float& mi, float& 
 // (storage order [row][tap][k]; packed [row][tap][k padded to red32] resp. FLAT rows of rowlen): pack_cl_rows_kernel's pass
 // over the master weights disappears.  Pad lanes / rows of the packed buffer keep the zeros of its first full packing.
 struct AdamPack { bf16_t* out; int red, red32, ntap; long rowlen; };
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2_sqrt, float gscale, int vec, AdamPack pk) {
+__device__ __forceinline__ void adam_four(float4& pp, const float4& gg, float4& mm, float4& vv, float lr, float b1, float b2, float eps, float wd,
+                                          float bc1, float bc2_sqrt, float gscale) {
+  adam_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+  adam_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+  adam_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+  adam_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+}
+// address of element e = 4 i of the packed forward operand: 32-bit unsigned divisions (n < 2^32, host-checked)
+__device__ __forceinline__ bf16_t* adam_pack_addr(const AdamPack& pk, unsigned e) {
+  const unsigned rt = e / (unsigned)pk.red, k = e - rt * (unsigned)pk.red;
+  const unsigned row = rt / (unsigned)pk.ntap, tap = rt - row * (unsigned)pk.ntap;
+  return pk.out + (long)row * pk.rowlen + (long)tap * pk.red32 + k;
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                                                  float wd, float bc1, float bc2_sqrt, float gscale, int vec, AdamPack pk) {
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
   const long n4 = vec ? n / 4 : 0;
+  // one 16-byte piece per stream and thread and iteration: two in flight (8 loads) measured SLOWER (1.71 -> 1.91 ms per U-Net step)
   for (long i = tid; i < n4; i += nthr) {
     float4 pp = ((float4*)p)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
     const float4 gg = ((const float4*)g)[i];
-    adam_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-    adam_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-    adam_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-    adam_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    adam_four(pp, gg, mm, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
-    if (pk.out) {  // red % 4 == 0 (host-checked): the four values share (row, tap)
-      const long e = i * 4, rt = e / pk.red; const int k = (int)(e - rt * pk.red);
-      const long row = rt / pk.ntap; const int tap = (int)(rt - row * pk.ntap);
-      bf16x4 o = (bf16x4){(short)f2bf(pp.x), (short)f2bf(pp.y), (short)f2bf(pp.z), (short)f2bf(pp.w)};
-      *(bf16x4*)(pk.out + row * pk.rowlen + (long)tap * pk.red32 + k) = o;
-    }
+    if (pk.out)   // red % 4 == 0 (host-checked): the four values share (row, tap)
+      *(bf16x4*)adam_pack_addr(pk, (unsigned)(i * 4)) = (bf16x4){(short)f2bf(pp.x), (short)f2bf(pp.y), (short)f2bf(pp.z), (short)f2bf(pp.w)};
   }
-  for (long i = n4 * 4 + tid; i < n; i += nthr) {
-    float pi = p[i], mi = m[i], vi = v[i];
-    adam_one(pi, g[i], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-    p[i] = pi; m[i] = mi; v[i] = vi;
+  for (long q = n4 * 4 + tid; q < n; q += nthr) {
+    float pi = p[q], mi = m[q], vi = v[q];
+    adam_one(pi, g[q], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    p[q] = pi; m[q] = mi; v[q] = vi;
   }
 }
 extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
@@ -1022,7 +1043,7 @@ extern "C" int rg_adam_step_pack(float* p, const float* g, float* m, float* v, i
   if (!p || !g || !m || !v || n < 0 || step < 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   const int vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
-  if (pk.out && (!vec || (n & 3))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: 16-byte aligned tensors with a multiple of 4 elements expected");
+  if (pk.out && (!vec || (n & 3) || n >= (1LL << 32))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: 16-byte aligned tensors with a multiple of 4 (and fewer than 2^32) elements expected");
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1, beta2, eps,
                      weight_decay, bc1, sqrtf(bc2), grad_scale, vec, pk);
   RG_CHECK_LAUNCH();
