@@ -4,9 +4,9 @@ this is the build's own component, defined by "N-GPU result == 1-GPU result on t
 (SURVEY.md §8e): gradients are summed over ranks and divided by world size right before each optimiser step.
 
 Samples are independent (InstanceNorm / no norm => no cross-sample statistics), so there is no other exchange.
-Gradients are reduced tensor by tensor, largest first, as asynchronous all-reduces that RCCL pipelines over
-the 7 xGMI links; flattening into buckets would only add a 1 GB copy for the U-Net (70 % of whose parameters
-sit in one 725 MB tensor).
+Large gradients are reduced tensor by tensor, largest first, as asynchronous all-reduces that RCCL pipelines over
+the 7 xGMI links (flattening them into buckets would only add a 1 GB copy for the U-Net, 70 % of whose parameters
+sit in one 725 MB tensor); small ones travel in flat buckets (GradSync).
 """
 import os
 
@@ -50,19 +50,37 @@ def _flat(g):
     raise RuntimeError("raygun_amd.GradSync: gradients must be dense (contiguous or channels-last)")
 
 
+BUCKET_BYTES = 32 << 20     # small gradients travel together in flat fp32 buckets of at most this size
+SMALL_BYTES = 1 << 20       # a gradient below this size is "small"
+
+
 class GradSync:
     """Callable(list_of_params): average .grad over all ranks (no-op for world size 1).
 
-    `attach(params)` additionally overlaps the exchange with the backward pass: a post-accumulate-grad hook starts the
-    asynchronous all-reduce of a parameter's gradient the moment autograd has produced it (RCCL runs it on its own stream
-    while the remaining backward kernels execute), and the call before the optimiser step only waits and scales.  For
-    the U-Net 70 % of the 1 GB of gradients is ready half-way through the backward pass.  Only valid where every
-    attached parameter receives its gradient in ONE backward pass per step (not for the split CycleGAN losses)."""
+    Large gradients (>= 1 MB: 99.9 % of the U-Net's 1.04 GB, 70 % of it ONE 725 MB tensor) are all-reduced in place, one
+    asynchronous RCCL call each, largest first — flattening them into buckets would only add a gigabyte of copies.  Small ones
+    (biases, the 12-channel levels: ~30 tensors of a few KB for the U-Net, ~70 for the CycleGAN's four nets) are packed into
+    flat fp32 buckets of <= 32 MB and reduced with one call per bucket instead of one ~10-us launch-bound collective each.
 
-    def __init__(self, group=None):
+    `attach(params)` additionally overlaps the exchange with the backward pass: a post-accumulate-grad hook starts the
+    asynchronous all-reduce of a large gradient the moment autograd has produced it (RCCL runs it on its own stream while
+    the remaining backward kernels execute); small gradients are collected by the hooks and their buckets are started by the
+    call before the optimiser step, behind the large tensors already on the wire.  For the U-Net 70 % of the gradient bytes are
+    ready half-way through the backward pass.  Only valid where every attached parameter receives its gradient in ONE backward
+    pass per step (not for the split CycleGAN losses, which call the object once per optimiser instead: LinkCycleLoss.py:121-135).
+
+    Expected cost on one 8-GPU node (xGMI full mesh, 7 links x ~153 GB/s per GPU): a bandwidth-optimal all-reduce
+    moves 2 (N-1)/N S per GPU — U-Net S = 1.04 GB: >= 1.7 ms over all seven links (reduce-scatter + all-gather across the mesh),
+    >= 11.9 ms if a single ring binds it to one link; CycleGAN generators 0.2 GB + discriminators 0.09 GB: 0.3 / 2.3 ms and
+    0.15 / 1.0 ms.  Against a 29-ms U-Net step the exchange hides behind the backward pass in either case."""
+
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, small_bytes=SMALL_BYTES):
         self.group = group
-        self._pending = {}   # id(param) -> (grad tensor, work handle)
+        self.bucket_bytes, self.small_bytes = int(bucket_bytes), int(small_bytes)
+        self._pending = {}   # id(param) -> (grad tensor, work handle)   large gradients started by a hook
+        self._small = {}     # id(param) -> grad tensor                   small gradients seen by a hook, bucketed at call time
         self._hooks = []
+        self.stats = dict(large=0, buckets=0, small=0)   # collectives issued by the last call
 
     def attach(self, params):
         if world_size() == 1:
@@ -77,11 +95,29 @@ class GradSync:
             h.remove()
         self._hooks = []
 
+    def _is_small(self, g):
+        return g.numel() * g.element_size() < self.small_bytes
+
     def _on_grad(self, p):
         g = p.grad
         if g is None:
             return
-        self._pending[id(p)] = (g, dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._is_small(g):
+            self._small[id(p)] = g
+        else:
+            self._pending[id(p)] = (g, dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _buckets(self, grads):
+        """Greedy fill in the given order: lists of gradients whose fp32 sizes sum to <= bucket_bytes."""
+        out, cur, size = [], [], 0
+        for g in grads:
+            n = g.numel() * 4
+            if cur and size + n > self.bucket_bytes:
+                out.append(cur); cur, size = [], 0
+            cur.append(g); size += n
+        if cur:
+            out.append(cur)
+        return out
 
     def __call__(self, params):
         ws = world_size()
@@ -89,16 +125,34 @@ class GradSync:
             return
         params = [p for p in params if p.grad is not None]
         started = [self._pending.pop(id(p)) for p in params if id(p) in self._pending]
+        for p in params:
+            self._small.pop(id(p), None)
         done = {id(g) for g, _ in started}
         rest = [p.grad for p in params if id(p.grad) not in done]
-        rest.sort(key=lambda g: -g.numel())
+        large = sorted((g for g in rest if not self._is_small(g)), key=lambda g: -g.numel())
+        small = [g for g in rest if self._is_small(g)]
         handles = [h for _, h in started]
-        for g in rest:
+        for g in large:
             handles.append(dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        inv = 1.0 / ws
+        flats = []
+        for bucket in self._buckets(small):
+            flat = torch.cat([_flat(g).reshape(-1).float() for g in bucket])
+            flats.append((flat, bucket, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        self.stats = dict(large=len(started) + len(large), buckets=len(flats), small=len(small))
         for h in handles:
             h.wait()
-        inv = 1.0 / ws
-        torch._foreach_mul_([g for g, _ in started] + rest, inv)
+        big = [g for g, _ in started] + large
+        if big:
+            torch._foreach_mul_(big, inv)
+        for flat, bucket, h in flats:
+            h.wait()
+            flat.mul_(inv)
+            off = 0
+            for g in bucket:
+                n = g.numel()
+                _flat(g).reshape(-1).copy_(flat[off:off + n])
+                off += n
 
 
 def broadcast_parameters(module, src=0):

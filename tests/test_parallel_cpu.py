@@ -25,10 +25,23 @@ def _worker(rank, world, port, out, overlap=False):
         sync.attach(net.parameters())
     loss = net(data[rank:rank + 1]).pow(2).mean()
     loss.backward()
-    if overlap:
-        assert len(sync._pending) == len(list(net.parameters()))
+    if overlap:  # hooks: large gradients are on the wire already, small ones wait for their bucket
+        assert len(sync._pending) + len(sync._small) == len(list(net.parameters()))
     sync(list(net.parameters()))
-    assert not sync._pending
+    assert not sync._pending and not sync._small
+    # all four tensors are far below 1 MB: they travel in ONE flat bucket, no per-tensor collective
+    assert sync.stats == dict(large=0, buckets=1, small=4), sync.stats
+    big = parallel.GradSync(small_bytes=64, bucket_bytes=256)   # thresholds scaled down: conv weights "large", biases bucketed
+    for q in net.parameters():
+        q.grad = torch.full_like(q, float(rank + 1))
+    big(list(net.parameters()))
+    assert big.stats["large"] == 1 and big.stats["small"] == 3 and big.stats["buckets"] >= 1, big.stats
+    assert all(torch.allclose(q.grad, torch.full_like(q, 1.5)) for q in net.parameters())
+    for q, gsave in zip(net.parameters(), [None] * 4):
+        q.grad = None
+    loss = net(data[rank:rank + 1]).pow(2).mean()
+    loss.backward()
+    sync(list(net.parameters()))
     # reference: one process, whole batch (mean over equal-sized samples == mean of per-sample means)
     ref = torch.nn.Sequential(torch.nn.Conv3d(1, 3, 3), torch.nn.InstanceNorm3d(3), torch.nn.ReLU(), torch.nn.Conv3d(3, 1, 1))
     ref.load_state_dict(net.state_dict())
