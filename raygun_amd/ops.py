@@ -394,6 +394,32 @@ def _wgrad(g, x, p, shape, channels_last=False):
     return dw
 
 
+def _wgrad_wpairs(g, x, p_args, shape, transposed):
+    """Weight gradient of a convolution with stride 2 / 3 taps / padding 1 along W on the stride-1 (kw-reuse, producer-wave) kernels:
+    the strided operand, seen through a zero-copy view as W/2 voxel PAIRS of 2C channels [even | odd], makes input index
+    2w + kw - 1 the pair w - 1 + kw' with  kw' = 0: [-, tap 0],  kw' = 1: [tap 1, tap 2]  — a stride-1 problem along W with two
+    taps and 2C channels (one of the four slots is zero: 4/3 of the FLOPs, on kernels that run 2-2.5x faster than the generic
+    strided one: 333 -> ~150 us for the generators' 64 -> 128 down convolution).  Returns None when the layout does not allow the
+    view (odd W, lane padding between voxels).  g: the stride-1 operand, x: the strided one (Conv3d: input; ConvTranspose3d: the
+    output gradient); shape: (A, B, KD, KH, 3) of the gradient, A = g's channels, B = x's."""
+    if os.environ.get("RAYGUN_AMD_WPAIR", "1") == "0":
+        return None
+    R, K, stride, padding = p_args
+    n, c, D, H, W = x.shape
+    if stride[2] != 2 or K[2] != 3 or padding[2] != 1 or W % 2 or c % 8 or x.stride(1) != 1 or x.stride(4) != c or not is_cl(x) or R[2] != W // 2:
+        return None
+    st = x.stride()
+    xv = torch.as_strided(x, (n, 2 * c, D, H, W // 2), (st[0], 1, st[2], st[3], 2 * c), x.storage_offset())
+    p = _conv_params(R=R, T=(K[0], K[1], 2), rstride=(stride[0], stride[1], 1), tbase=(-padding[0], -padding[1], -1), tstep=(1, 1, 1),
+                     ostride=(1, 1, 1), ooffset=(0, 0, 0), cout=shape[0])
+    d2 = _wgrad(g, xv, p, (shape[0], 2 * c, K[0], K[1], 2))
+    dw = torch.empty(shape, dtype=torch.float32, device=g.device)
+    dw[..., 0] = d2[:, c:, :, :, 0]
+    dw[..., 1] = d2[:, :c, :, :, 1]
+    dw[..., 2] = d2[:, c:, :, :, 1]
+    return dw
+
+
 def _act_bwd_bias(gy, y, act, slope, want_bias):
     """g = gy*act'(y) (new tensor unless act == none), db = per-channel sum (fp32) or None."""
     if act == "none" and not want_bias:
@@ -546,9 +572,12 @@ class _Conv3d(Function):
             else:
                 _scatter_conv(g, weight, None, gx, stride, padding, K, swap=1, act="none", slope=0.0)
         if ctx.needs_input_grad[1]:
-            p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
-                             ooffset=(0, 0, 0), cout=weight.shape[0])
-            dw = _wgrad(g, x, p, weight.shape, channels_last=is_cl_weight(weight)).to(weight.dtype)
+            dw = _wgrad_wpairs(g, x, (O, K, stride, padding), tuple(weight.shape), False) if stride[2] == 2 else None
+            if dw is None:
+                p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
+                                 ooffset=(0, 0, 0), cout=weight.shape[0])
+                dw = _wgrad(g, x, p, weight.shape, channels_last=is_cl_weight(weight))
+            dw = dw.to(weight.dtype)
         if db is not None:
             db = db.to(weight.dtype)
         return gx, dw, db, None, None, None, None, None
@@ -673,7 +702,10 @@ class _ConvTranspose3d(Function):
             gx = cl_empty(n, cin, D, H, W, x.device)
             _igemm(g, pack_weights(weight, swap=0), None, gx, p)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(x, g, p, weight.shape).to(weight.dtype)
+            dw = _wgrad_wpairs(x, g, ((D, H, W), K, stride, padding), tuple(weight.shape), True) if stride[2] == 2 else None
+            if dw is None:
+                dw = _wgrad(x, g, p, weight.shape)
+            dw = dw.to(weight.dtype)
         if db is not None:
             db = db.to(weight.dtype)
         return gx, dw, db, None, None, None, None, None

@@ -459,3 +459,38 @@ def test_packed_weight_cache_invalidation():
     with torch.no_grad():
         conv.weight.mul_(0.5)             # bumps the version: nothing to do
     assert relerr(conv(x), F.conv3d(x.cpu(), bf(conv.weight.detach().cpu()), conv.bias.detach().cpu())) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp", [(64, 128, (8, 8, 12)), (16, 24, (6, 10, 8)), (128, 64, (4, 6, 8))])
+def test_strided_conv_weight_gradient_through_w_pairs(cin, cout, sp, monkeypatch):
+    """Stride-2 / k3 / pad-1 convolutions and transposed convolutions take their weight gradient through ops._wgrad_wpairs (the
+    strided operand viewed as W-pairs of 2C channels, stride-1 kernels): against torch fp32 on the CPU, and against the generic
+    strided kernel (RAYGUN_AMD_WPAIR=0)."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    x0 = rnd((2, cin) + sp, 41); w0 = rnd((cout, cin, 3, 3, 3), 42, -0.1, 0.1)
+    xr, wr = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, None, stride=2, padding=1)
+    go = rnd(tuple(yr.shape), 43)
+    (gw_ref,) = torch.autograd.grad(yr, wr, go)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RAYGUN_AMD_WPAIR", flag)
+        xd, wd = x0.clone().to(dev).requires_grad_(), w0.clone().to(dev).requires_grad_()
+        y = ops.conv3d(xd, wd, None, stride=2, padding=1)
+        (got[flag],) = torch.autograd.grad(y, wd, go.to(dev).to(y.dtype))
+        assert relerr(got[flag], gw_ref) <= TOL
+    assert relerr(got["1"], got["0"].cpu()) <= 2e-3          # same bf16 operands, fp32 accumulation in a different order
+    # transposed convolution (generator up path, networks/ResNet.py:325-333): weight (cin, cout, 3,3,3), output_padding 1
+    wt0 = rnd((cin, cout, 3, 3, 3), 44, -0.1, 0.1)
+    xr, wr = x0.clone().requires_grad_(), wt0.clone().requires_grad_()
+    yr = F.conv_transpose3d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    go = rnd(tuple(yr.shape), 45)
+    (gw_ref,) = torch.autograd.grad(yr, wr, go)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RAYGUN_AMD_WPAIR", flag)
+        xd, wd = x0.clone().to(dev).requires_grad_(), wt0.clone().to(dev).requires_grad_()
+        y = ops.conv_transpose3d(xd, wd, None, stride=2, padding=1, output_padding=1)
+        (gw,) = torch.autograd.grad(y, wd, go.to(dev).to(y.dtype))
+        assert relerr(gw, gw_ref) <= TOL, flag
