@@ -150,20 +150,48 @@ class ConvTranspose3d(nn.ConvTranspose3d):
         return self.run(x)
 
 
+def _instance_norm_run(self, x, act, slope, residual, base_forward, enter=lambda t: t):
+    """Shared by InstanceNorm3d / InstanceNorm2d.  affine=False runs on the HIP kernels, with or without running statistics
+    (torch.nn.modules.instancenorm semantics: instance statistics normalise in training mode and update
+    running_mean / running_var — unbiased variance, `momentum`, averaged over the batch — and eval mode normalises with the
+    running statistics); the affine form uses torch's op."""
+    if self.affine:
+        y = passthrough(base_forward, x)
+        if residual is not None:
+            y = ops.add(enter(y), residual)
+        return ops.activation(enter(y), act, slope)
+    x = enter(x)
+    if self.track_running_stats and not self.training:
+        rstd = torch.rsqrt(self.running_var.float() + self.eps)
+        return ops.norm_fixed(x, self.running_mean, rstd, act, slope, residual)
+    if not self.track_running_stats:
+        return ops.instance_norm(x, self.eps, act, slope, residual)
+    y, mr = ops.instance_norm(x, self.eps, act, slope, residual, return_stats=True)
+    with torch.no_grad():
+        n, c = x.shape[0], x.shape[1]
+        cnt = x.shape[2] * x.shape[3] * x.shape[4]
+        mean = mr[:, 0].view(n, c).mean(0)
+        var = ((1.0 / (mr[:, 1] * mr[:, 1]) - self.eps).clamp_(min=0) * (cnt / max(cnt - 1, 1))).view(n, c).mean(0)
+        m = self.momentum
+        if m is None:   # cumulative moving average
+            self.num_batches_tracked += 1
+            m = 1.0 / float(self.num_batches_tracked)
+        elif self.num_batches_tracked is not None:
+            self.num_batches_tracked += 1
+        self.running_mean.mul_(1 - m).add_(mean.to(self.running_mean.dtype), alpha=m)
+        self.running_var.mul_(1 - m).add_(var.to(self.running_var.dtype), alpha=m)
+    return y
+
+
 class InstanceNorm3d(nn.InstanceNorm3d):
-    """affine=False, track_running_stats=False runs on the HIP kernels (the only form get_network builds for the
-    hot path: systems/BaseSystem.py:193-199, networks/ResNet.py:231-262 default).  Other forms use torch's op."""
+    """affine=False runs on the HIP kernels — the plain form get_network builds for the hot path (systems/BaseSystem.py:193-199,
+    networks/ResNet.py:231-262 default) and the running-statistics form of the experiment configs; affine uses torch's op."""
 
     def hip_ok(self):
-        return not self.affine and not self.track_running_stats
+        return not self.affine
 
     def run(self, x, act="none", slope=0.0, residual=None):
-        if not self.hip_ok():
-            y = passthrough(super().forward, x)
-            if residual is not None:
-                y = ops.add(y, residual)
-            return ops.activation(y, act, slope)
-        return ops.instance_norm(x, self.eps, act, slope, residual)
+        return _instance_norm_run(self, x, act, slope, residual, super().forward)
 
     @scoped
     def forward(self, x):
@@ -241,18 +269,14 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 
 class InstanceNorm2d(nn.InstanceNorm2d):
-    """As InstanceNorm3d: the plain form runs on the HIP kernels, affine / running-stats forms on torch's op."""
+    """As InstanceNorm3d, on the (N,C,1,H,W) view: incl. `InstanceNorm2d(track_running_stats=True, momentum=0.01)` of the published
+    2-D CycleGAN configs (reference tests/torch/systems/CycleGAN_conf.json:62)."""
 
     def hip_ok(self):
-        return not self.affine and not self.track_running_stats
+        return not self.affine
 
     def run(self, x, act="none", slope=0.0, residual=None):
-        if not self.hip_ok():
-            y = passthrough(super().forward, x)
-            if residual is not None:
-                y = ops.add(ops.enter(y), residual)
-            return ops.activation(ops.enter(y), act, slope)
-        return ops.instance_norm(ops.enter(x), self.eps, act, slope, residual)
+        return _instance_norm_run(self, x, act, slope, residual, super().forward, ops.enter)
 
     @scoped
     def forward(self, x):

@@ -933,10 +933,11 @@ class _InstanceNorm(Function):
                                        C.byref(desc(y)), ACT[act], float(slope), _stream()), "rg_instnorm_apply")
         ctx.save_for_backward(x, mr, y if act != "none" else None)
         ctx.cfg = (act, slope, res is not None)
-        return y
+        ctx.mark_non_differentiable(mr)
+        return y, mr
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gmr=None):
         x, mr, y = ctx.saved_tensors
         act, slope, has_res = ctx.cfg
         gy = as_cl(gy)
@@ -954,8 +955,51 @@ class _InstanceNorm(Function):
         return gx, (gy if has_res and ctx.needs_input_grad[1] else None), None, None, None
 
 
-def instance_norm(x, eps=1e-5, act="none", slope=0.0, residual=None):
-    return _InstanceNorm.apply(x, residual, float(eps), act, float(slope))
+def instance_norm(x, eps=1e-5, act="none", slope=0.0, residual=None, return_stats=False):
+    """return_stats: also the float32 (N*C, 2) tensor of (mean, 1/sqrt(biased var + eps)) per instance and channel."""
+    y, mr = _InstanceNorm.apply(x, residual, float(eps), act, float(slope))
+    return (y, mr.view(-1, 2)) if return_stats else y
+
+
+class _NormFixed(Function):
+    """y = act((x - mean[c]) * rstd[c]) [+ residual] with GIVEN per-channel statistics — InstanceNorm(track_running_stats=True) in
+    eval mode (the CycleGAN's `freeze_norms_at` / set_norm_mode("fix_norms"), networks/utils.py:31-42, models/FreezableModel.py):
+    the apply kernel of the instance norm with a constant table; backward is the same kernel with mean 0 on g = gy * act'(y)."""
+
+    @staticmethod
+    def forward(ctx, x, res, mean, rstd, act, slope):
+        _require_cuda(x, "norm_fixed")
+        x = as_cl(x)
+        if res is not None:
+            if act != "none":
+                raise RuntimeError("raygun_amd.norm_fixed: residual add is fused only without activation")
+            res = as_cl(res)
+        n, c, d, h, w = x.shape
+        mr = torch.stack([mean.float(), rstd.float()], 1).repeat(n, 1).contiguous().view(-1)       # (n*c*2,)
+        y = cl_empty(n, c, d, h, w, x.device)
+        _lib.check(_L().rg_instnorm_apply(C.byref(desc(x)), C.c_void_p(mr.data_ptr()), C.byref(desc(res)) if res is not None else None,
+                                          C.byref(desc(y)), ACT[act], float(slope), _stream()), "rg_instnorm_apply")
+        ctx.save_for_backward(torch.stack([torch.zeros_like(rstd, dtype=torch.float32), rstd.float()], 1).repeat(n, 1).contiguous().view(-1),
+                              y if act != "none" else None)
+        ctx.cfg = (act, slope, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        mr0, y = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        gy = as_cl(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            g, _ = _act_bwd_bias(gy, y, act, slope, False)
+            gx = cl_empty(*gy.shape, gy.device)
+            _lib.check(_L().rg_instnorm_apply(C.byref(desc(g)), C.c_void_p(mr0.data_ptr()), None, C.byref(desc(gx)), ACT["none"], 0.0, _stream()),
+                       "rg_instnorm_apply")
+        return gx, (gy if has_res and ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+def norm_fixed(x, mean, rstd, act="none", slope=0.0, residual=None):
+    return _NormFixed.apply(x, residual, mean, rstd, act, float(slope))
 
 
 # ---------------------------------------------------------------------------------------------- padding / add

@@ -41,11 +41,13 @@ class ConvPass(nn.Module):
     _raygun_amd = True
 
     def __init__(self, input_nc, output_nc, kernel_sizes, activation, padding="valid", residual=False,
-                 padding_mode="reflect", norm_layer=None):
+                 padding_mode="reflect", norm_layer=None, final=False):
+        """`final` (ResidualUNet.py:22,94-99,123-126): the block is the network's output — its last activation is omitted."""
         super().__init__()
         self.activation = _activation_instance(activation)
         self.residual = residual
         self.padding = padding
+        self.final = final
         norm_layer = hipnn.hip_layer(norm_layer)
         layers = []
         for i, kernel_size in enumerate(kernel_sizes):
@@ -54,12 +56,13 @@ class ConvPass(nn.Module):
             layers.append(conv(input_nc, output_nc, tuple(int(k) for k in kernel_size), padding=padding, padding_mode=padding_mode))
             if residual and i == 0:
                 groups = input_nc if input_nc < output_nc else output_nc
-                # grouped 1x1 map of the residual variant: torch's own op (not on the benchmark path)
+                # grouped 1x1 map of the residual variant (UNet.py:70-83): a torch module for its parameter / state_dict key;
+                # forward() evaluates it as a dense 1x1 convolution on the HIP kernel (block-sparse weight, see _init_map)
                 self.x_init_map = getattr(nn, f"Conv{self.dims}d")(input_nc, output_nc, tuple(np.ones(self.dims, dtype=int)), padding=padding,
                                             padding_mode=padding_mode, bias=False, groups=groups)
             if norm_layer is not None:
                 layers.append(norm_layer(output_nc))
-            if not (residual and i == (len(kernel_sizes) - 1)):
+            if not ((residual and i == (len(kernel_sizes) - 1)) or (final and i == (len(kernel_sizes) - 1))):
                 layers.append(self.activation)
             input_nc = output_nc
         self.conv_pass = hipnn.FusedSequential(*layers)
@@ -72,12 +75,27 @@ class ConvPass(nn.Module):
         if not self.residual:
             return self.conv_pass(x)
         res = self.conv_pass(x)
-        init_x = ops.enter(hipnn.passthrough(self.x_init_map, x))
+        init_x = self._init_map(x)
         if self.padding.lower() == "valid":
             init_x = self.crop(init_x, res.size()[-3:] if res.dim() == 5 else res.size()[-self.dims:])
         y = ops.add(init_x, res)
+        if self.final:
+            return y
         a = hipnn.act_of(self.activation)
         return ops.activation(y, a[0], a[1]) if a is not None else hipnn.passthrough(self.activation, y)
+
+    def _init_map(self, x):
+        """x_init_map(x): the grouped, bias-free 1x1 convolution as a DENSE 1x1 convolution whose (Cout, Cin) weight is zero outside
+        the groups — output channel o of group g = o // (Cout / groups) sees input channels [g * Cin/groups, (g+1) * Cin/groups).
+        The scatter is differentiable, so the grouped parameter gets its gradient; the arithmetic runs on the igemm kernels."""
+        m = self.x_init_map
+        if not x.is_cuda or any(k != 1 for k in m.kernel_size):
+            return ops.enter(hipnn.passthrough(m, x))
+        cout, ipg = m.weight.shape[0], m.weight.shape[1]
+        cin, opg = ipg * m.groups, cout // m.groups
+        cols = (torch.arange(cout, device=x.device) // opg)[:, None] * ipg + torch.arange(ipg, device=x.device)[None, :]
+        dense = torch.zeros(cout, cin, dtype=m.weight.dtype, device=x.device).scatter(1, cols, m.weight.reshape(cout, ipg))
+        return ops.conv3d(ops.enter(x), dense.reshape(cout, cin, 1, 1, 1), None)
 
 
 class ConvDownsample(nn.Module):
@@ -261,7 +279,7 @@ class UNet(nn.Module):
             ConvPass(ngf * fmap_inc_factor ** level + ngf * fmap_inc_factor ** (level + 1),
                      ngf * fmap_inc_factor ** level if output_nc is None or level != 0 else output_nc,
                      kernel_size_up[level], activation=activation, padding=padding_type, residual=self.residual,
-                     norm_layer=norm_layer)
+                     norm_layer=norm_layer, **({"final": level == 0} if self._final_output_block else {}))
             for level in range(self.num_levels - 1)]) for _ in range(num_heads)])
 
     def rec_forward(self, level, f_in):
@@ -312,6 +330,8 @@ class UNet(nn.Module):
         with hipnn.scope():
             y = ops.upcat_conv3d(f_left, g_out, target, conv.weight, conv.bias, a[0], a[1])
             return rc.conv_pass.run(y, start=2)
+
+    _final_output_block = False   # ResidualUNet: the level-0 right ConvPass is built with final=True (ResidualUNet.py:636)
 
     @hipnn.scoped
     def forward(self, x):

@@ -141,6 +141,8 @@ class BaseSystem:
         add_final = True
         if net_type == "unet":
             net = networks.UNet(**self.get_downsample_factors(net_kwargs))
+        elif net_type == "residualunet":   # BaseSystem.py:184-187
+            net = networks.ResidualUNet(**self.get_downsample_factors(net_kwargs))
         elif net_type == "resnet":
             net = networks.ResNet(self.ndims, **net_kwargs)
         elif net_type == "patchdiscriminator":

@@ -233,20 +233,20 @@ def fx_instnorm():
     save("instnorm3d", y=y.detach().numpy(), gx=xi.grad.numpy())
 
 
-def _cyc_cfg(nd, gk, dk, loss_type, lr=5e-4):
+def _cyc_cfg(nd, gk, dk, loss_type, lr=5e-4, d_lr=None):
     return dict(common_voxel_size=[1] * 3, ndims=nd, gnet_type="resnet", gnet_kwargs=gk, dnet_kwargs=dk,
                 loss_type=loss_type, loss_kwargs={},
-                g_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr))
+                g_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr if d_lr is None else d_lr))
 
 
-def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2):
-    cfg = _cyc_cfg(nd, dict(gk), dict(dk), loss_type)
+def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_lr=5e-4, d_lr=5e-4):
+    cfg = _cyc_cfg(nd, dict(gk), dict(dk), loss_type, g_lr, d_lr)
     if loss_kwargs:
         cfg["loss_kwargs"] = loss_kwargs
     rs = RCycleGAN(cfg)
     rs.setup_networks(); rs.setup_model(); rs.setup_optimization()
     model, loss, opts = O.build_cyclegan(nd, dict(gk), dict(dk), split=(loss_type == "split"),
-                                         g_lr=5e-4, d_lr=5e-4, betas=(0.5, 0.999), loss_kwargs=loss_kwargs, init=False)
+                                         g_lr=g_lr, d_lr=d_lr, betas=(0.5, 0.999), loss_kwargs=loss_kwargs, init=False)
     nets_r = dict(G1=rs.netG1, G2=rs.netG2, D1=rs.netD1, D2=rs.netD2)
     nets_o = dict(G1=model.netG1, G2=model.netG2, D1=loss.netD1, D2=loss.netD2)
     for i, k in enumerate(nets_r):
@@ -272,8 +272,11 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2):
             close(p.detach().numpy(), q.detach().numpy(), 5e-5, f"{tag}.w.{k}.{n}")
         wsum[k] = [float(sum(p.double().sum() for p in nets_r[k].parameters())),
                    float(sum(p.double().abs().sum() for p in nets_r[k].parameters()))]
-    save(tag, loss_dicts=json.dumps(recs), weight_sums=json.dumps(wsum), fake_B=fB.detach().numpy(),
-         meta=json.dumps(dict(shape=list(shape), loss_type=loss_type, lr=5e-4, betas=[0.5, 0.999], iters=iters,
+    from raygun.torch.networks.utils import get_running_norm_stats
+    rm, rv = get_running_norm_stats(rs.netG1)
+    extra = {} if rm is None else dict(running_mean_G1=rm.numpy(), running_var_G1=rv.numpy())
+    save(tag, loss_dicts=json.dumps(recs), weight_sums=json.dumps(wsum), fake_B=fB.detach().numpy(), **extra,
+         meta=json.dumps(dict(shape=list(shape), loss_type=loss_type, lr=g_lr, d_lr=d_lr, betas=[0.5, 0.999], iters=iters,
                               gk={k: str(v) for k, v in gk.items()}, dk={k: str(v) for k, v in dk.items()},
                               state_keys_model=list(rs.model.state_dict().keys()))))
 
@@ -293,6 +296,18 @@ def fx_cyclegans(big):
     d2 = dict(input_nc=1, ngf=ngf, n_layers=4)
     fx_cyclegan("cyclegan_step_split_2d256", 2, (1, 1, 256, 256), g2, d2, "split")
     fx_cyclegan("cyclegan_step_link_2d256", 2, (1, 1, 256, 256), g2, d2, "link", iters=1)
+
+
+def fx_cyclegan_conf1():
+    """BASELINE config[0] / SURVEY 8d "Config 1" as specified: tests/torch/systems/CycleGAN_conf.json:17-91 with side_length 256 —
+    resnet generators ngf 64 / 9 blocks / no downsampling / InstanceNorm2d(track_running_stats=True, momentum=0.01) / "same",
+    4-layer patch discriminators ngf 64, split loss, lambda cycled 3 / identity 0, Adam G lr 4e-5, D lr 4e-6, betas (0.5, 0.999)."""
+    INr = functools.partial(torch.nn.InstanceNorm2d, track_running_stats=True, momentum=0.01)
+    g2 = dict(input_nc=1, output_nc=1, ngf=64, n_blocks=9, n_downsampling=0, norm_layer=INr, padding_type="same")
+    d2 = dict(input_nc=1, ngf=64, n_layers=4)
+    lk = {"g_lambda_dict": {s_: {"l1_loss": {"cycled": 3, "identity": 0}, "gan_loss": {"fake": 1, "cycled": 0}} for s_ in "AB"},
+          "d_lambda_dict": {s_: {"real": 1, "fake": 1, "cycled": 0} for s_ in "AB"}}
+    fx_cyclegan("cyclegan_step_split_2d256_conf1", 2, (1, 1, 256, 256), g2, d2, "split", loss_kwargs=lk, iters=2, g_lr=4e-5, d_lr=4e-6)
 
 
 def fx_misc():
@@ -353,10 +368,36 @@ def fx_structure():
     print("  wrote structure.json")
 
 
+def fx_residual_unet():
+    """raygun.torch.networks.ResidualUNet (ResidualUNet.py:364-701) — no oracle restatement exists for it: the fixtures hold the
+    REFERENCE's outputs and gradients, the GPU build is compared with them directly (tests/test_networks_gpu.py)."""
+    from raygun.torch.networks.ResidualUNet import ResidualUNet as RResUNet
+    for name, kw, shape, seed in (
+            ("residual_unet_relu", dict(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True,
+                                        residual=True), (1, 1, 36, 36, 36), 91),
+            ("residual_unet_smooth", dict(input_nc=4, ngf=4, fmap_inc_factor=3, downsample_factors=[(2, 2, 2)], constant_upsample=True,
+                                          residual=True, activation="Tanh"), (1, 4, 36, 36, 36), 92),
+            ("residual_unet_plain_same", dict(input_nc=2, ngf=8, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True,
+                                              residual=False, padding_type="same", output_nc=2, activation="Tanh"), (1, 2, 16, 16, 16), 93)):
+        ref = RResUNet(**kw)
+        load_w(ref, seed)
+        x = T(synth.uniform(shape, seed + 1))
+        ry, rgx, rgw = fwd_bwd(ref, x, seed + 2)
+        arrs = {f"y{i}": a for i, a in enumerate(ry)}
+        arrs["gx"] = rgx
+        for k in rgw:
+            arrs["gw::" + k] = rgw[k]
+        kwj = dict(kw); kwj["downsample_factors"] = [list(f) for f in kw["downsample_factors"]]
+        arrs["meta"] = json.dumps(dict(in_shape=list(shape), seed=seed, kwargs=kwj, keys=list(ref.state_dict().keys())))
+        save(name, **arrs)
+
+
 FIXTURES = {
+    "residual_unet": fx_residual_unet,
     "convpass": fx_convpass, "maxdown": fx_maxdown, "upsample": fx_upsample, "unet_small": fx_unet_small,
     "resnet": fx_resnet, "smooth": fx_smooth, "instnorm": fx_instnorm, "misc": fx_misc, "structure": fx_structure,
     "cyclegan": lambda: fx_cyclegans(False),
+    "cyclegan_conf1": fx_cyclegan_conf1,
     "mtlsd_100": lambda: fx_mtlsd(100, "mtlsd_100", False),
     "mtlsd_196": lambda: fx_mtlsd(196, "mtlsd_196_sampled", True),
 }

@@ -104,3 +104,51 @@ def test_train_step_loss_trajectory_2d_config0():
         for k in theirs:
             scale = max(abs(theirs[k]), 0.05, abs(theirs[k] - ref[0][k]))
             assert abs(mine[k] - theirs[k]) <= tol * scale, (it, k, mine[k], theirs[k])
+
+
+def test_train_step_config1_as_specified_running_stats():
+    """SURVEY 8d "Config 1" as specified, on the GPU: InstanceNorm2d(track_running_stats=True, momentum=0.01) on the HIP kernels
+    (hipnn._instance_norm_run), ngf 64, 9 blocks, 4-layer patch D, split loss, lambda 3, Adam 4e-5 / 4e-6 — loss trajectory and
+    the generators' running statistics against the reference-generated fixture; then eval mode (`freeze_norms_at`:
+    set_norm_mode("fix_norms")) normalises with the running statistics and still trains."""
+    from raygun_amd import hipnn
+    from raygun_amd.torch.networks.utils import get_running_norm_stats, set_norm_mode
+    from raygun_amd.torch.systems import CycleGAN
+    fx = np.load(os.path.join(G, "cyclegan_step_split_2d256_conf1.npz"))
+    ref = json.loads(str(fx["loss_dicts"]))
+    INr = functools.partial(torch.nn.InstanceNorm2d, track_running_stats=True, momentum=0.01)
+    lk = {"g_lambda_dict": {s_: {"l1_loss": {"cycled": 3, "identity": 0}, "gan_loss": {"fake": 1, "cycled": 0}} for s_ in "AB"},
+          "d_lambda_dict": {s_: {"real": 1, "fake": 1, "cycled": 0} for s_ in "AB"}}
+    cfg = dict(common_voxel_size=[1, 1], ndims=2, gnet_type="resnet",
+               gnet_kwargs=dict(input_nc=1, output_nc=1, ngf=64, n_blocks=9, n_downsampling=0, norm_layer=INr, padding_type="same"),
+               dnet_kwargs=dict(input_nc=1, ngf=64, n_layers=4), loss_type="split", loss_kwargs=lk,
+               g_optim_kwargs=dict(betas=[0.5, 0.999], lr=4e-5), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=4e-6))
+    s = CycleGAN(cfg)
+    s.setup_networks()
+    dev = torch.device("cuda")
+    for i, k in enumerate(["netG1", "netG2", "netD1", "netD2"]):
+        net = getattr(s, k)
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i))
+        net.to(dev)
+    norms = [m for m in s.netG1.modules() if isinstance(m, hipnn.InstanceNorm2d)]
+    assert norms and all(m.track_running_stats and m.hip_ok() for m in norms)
+    s.setup_model(); s.setup_optimization()
+    recs, fB = run_steps(s, dev, len(ref), (1, 1, 256, 256))
+    for it, (mine, theirs) in enumerate(zip(recs, ref)):
+        assert set(mine) == set(theirs)
+        for k in theirs:
+            scale = max(abs(theirs[k]), 0.05, abs(theirs[k] - ref[0][k]))
+            assert abs(mine[k] - theirs[k]) <= (0.02 if it == 0 else 0.06) * scale, (it, k, mine[k], theirs[k])
+    rm, rv = get_running_norm_stats(s.netG1)
+    a, b = rm.float().cpu().numpy(), fx["running_mean_G1"]
+    assert np.abs(a - b).max() <= 0.03 * np.abs(b).max() + 1e-4
+    a, b = rv.float().cpu().numpy(), fx["running_var_G1"]
+    assert np.abs(a - b).max() <= 0.03 * np.abs(b).max()
+    # frozen norms: eval-mode normalisation from the running statistics, gradients still flow
+    set_norm_mode(s.netG1, "fix_norms")
+    x = torch.from_numpy(synth.uniform((1, 1, 64, 64), 5)).to(dev).requires_grad_()
+    before = [m.running_mean.clone() for m in norms]
+    y = s.netG1(x)
+    y.float().pow(2).mean().backward()
+    assert all(torch.equal(m.running_mean, b0) for m, b0 in zip(norms, before))       # eval mode does not update them
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0

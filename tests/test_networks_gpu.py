@@ -267,3 +267,27 @@ def test_f16_storage_training_step_small_unet():
     for k in fx.files:
         if k.startswith("gw::") and np.abs(fx[k]).max() >= 1e-3:
             assert l2rel(params[k[4:]].grad, fx[k]) <= 8e-3, k
+
+
+@pytest.mark.parametrize("name", ["residual_unet_relu", "residual_unet_smooth", "residual_unet_plain_same"])
+def test_residual_unet_matches_reference(name):
+    """raygun_amd.torch.networks.ResidualUNet (residual ConvPasses with their grouped 1x1 map, `final` output
+    block, input added to the output) against fixtures generated from the reference class itself
+    (tests/golden/make_golden.py:fx_residual_unet): state_dict keys, forward; gradients for the smooth (Tanh) variants."""
+    from raygun_amd.torch.networks import ResidualUNet
+    fx = np.load(os.path.join(G, name + ".npz"))
+    meta = json.loads(str(fx["meta"]))
+    kw = meta["kwargs"]; kw["downsample_factors"] = [tuple(f) for f in kw["downsample_factors"]]
+    net = ResidualUNet(**kw)
+    assert list(net.state_dict().keys()) == meta["keys"]
+    net, x, ys, gs = run_fixture(net, fx, torch.device("cuda"))
+    assert ys[0].dtype == torch.float32 and l2rel(ys[0], fx["y0"]) <= 3e-2
+    if "relu" not in name:
+        assert l2rel(x.grad, fx["gx"]) <= 4e-2
+        params = dict(net.named_parameters())
+        checked = 0
+        for k in fx.files:
+            if k.startswith("gw::") and np.abs(fx[k]).max() >= 1e-3:
+                assert l2rel(params[k[4:]].grad, fx[k]) <= 4e-2, k
+                checked += 1
+        assert checked > 4

@@ -494,3 +494,32 @@ def test_strided_conv_weight_gradient_through_w_pairs(cin, cout, sp, monkeypatch
         y = ops.conv_transpose3d(xd, wd, None, stride=2, padding=1, output_padding=1)
         (gw,) = torch.autograd.grad(y, wd, go.to(dev).to(y.dtype))
         assert relerr(gw, gw_ref) <= TOL, flag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd", [3, 2])
+def test_instance_norm_running_stats_matches_torch(nd):
+    """hipnn.InstanceNorm{2,3}d(track_running_stats=True, momentum) against torch.nn on the CPU: training mode (output, gradient,
+    running mean / unbiased running var after two batches) and eval mode (normalisation by the running statistics, gradient)."""
+    from raygun_amd import hipnn
+    dev = torch.device("cuda")
+    shape = (2, 16, 5, 6, 7) if nd == 3 else (2, 16, 9, 11)
+    mine = getattr(hipnn, f"InstanceNorm{nd}d")(16, track_running_stats=True, momentum=0.1).to(dev)
+    ref = getattr(torch.nn, f"InstanceNorm{nd}d")(16, track_running_stats=True, momentum=0.1)
+    for it in range(2):
+        x0 = rnd(shape, 60 + it, -2, 3)
+        xr = x0.clone().requires_grad_(); xd = x0.clone().to(dev).requires_grad_()
+        yr = ref(xr); y = mine(xd)
+        go = rnd(shape, 70 + it)
+        yr.backward(go); y.backward(go.to(dev))
+        assert relerr(y, yr) <= TOL and relerr(xd.grad, xr.grad) <= 2 * TOL
+    assert relerr(mine.running_mean, ref.running_mean) <= 1e-2 and relerr(mine.running_var, ref.running_var) <= 1e-2
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    mine.eval(); ref.eval()
+    ref.running_mean.copy_(mine.running_mean.cpu()); ref.running_var.copy_(mine.running_var.cpu())
+    x0 = rnd(shape, 80, -2, 3)
+    xr = x0.clone().requires_grad_(); xd = x0.clone().to(dev).requires_grad_()
+    yr = ref(xr); y = mine(xd)
+    go = rnd(shape, 81)
+    yr.backward(go); y.backward(go.to(dev))
+    assert relerr(y, yr) <= TOL and relerr(xd.grad, xr.grad) <= TOL
