@@ -172,12 +172,7 @@ def _instance_norm_run(self, x, act, slope, residual, base_forward, enter=lambda
         cnt = x.shape[2] * x.shape[3] * x.shape[4]
         mean = mr[:, 0].view(n, c).mean(0)
         var = ((1.0 / (mr[:, 1] * mr[:, 1]) - self.eps).clamp_(min=0) * (cnt / max(cnt - 1, 1))).view(n, c).mean(0)
-        m = self.momentum
-        if m is None:   # cumulative moving average
-            self.num_batches_tracked += 1
-            m = 1.0 / float(self.num_batches_tracked)
-        elif self.num_batches_tracked is not None:
-            self.num_batches_tracked += 1
+        m = self.momentum if self.momentum is not None else 0.0   # F.instance_norm's rule; num_batches_tracked is not touched by torch either
         self.running_mean.mul_(1 - m).add_(mean.to(self.running_mean.dtype), alpha=m)
         self.running_var.mul_(1 - m).add_(var.to(self.running_var.dtype), alpha=m)
     return y

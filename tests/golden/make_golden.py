@@ -375,8 +375,9 @@ def fx_residual_unet():
     for name, kw, shape, seed in (
             ("residual_unet_relu", dict(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True,
                                         residual=True), (1, 1, 36, 36, 36), 91),
+            # smooth variants (Tanh, strided-conv downsampling: no ReLU / max-pool decisions) carry the gradient comparison
             ("residual_unet_smooth", dict(input_nc=4, ngf=4, fmap_inc_factor=3, downsample_factors=[(2, 2, 2)], constant_upsample=True,
-                                          residual=True, activation="Tanh"), (1, 4, 36, 36, 36), 92),
+                                          residual=True, activation="Tanh", downsample_method="convolve"), (1, 4, 38, 38, 38), 92),
             ("residual_unet_plain_same", dict(input_nc=2, ngf=8, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True,
                                               residual=False, padding_type="same", output_nc=2, activation="Tanh"), (1, 2, 16, 16, 16), 93)):
         ref = RResUNet(**kw)

@@ -144,11 +144,18 @@ def test_train_step_config1_as_specified_running_stats():
     assert np.abs(a - b).max() <= 0.03 * np.abs(b).max() + 1e-4
     a, b = rv.float().cpu().numpy(), fx["running_var_G1"]
     assert np.abs(a - b).max() <= 0.03 * np.abs(b).max()
-    # frozen norms: eval-mode normalisation from the running statistics, gradients still flow
-    set_norm_mode(s.netG1, "fix_norms")
+    # frozen norms: eval-mode normalisation from the running statistics, gradients still flow.  With momentum 1 one training-mode
+    # pass makes the running statistics THIS input's statistics, so the eval-mode output must reproduce the training-mode one
+    # (biased vs unbiased variance: a factor 4096/4095 at 64 x 64)
     x = torch.from_numpy(synth.uniform((1, 1, 64, 64), 5)).to(dev).requires_grad_()
+    for m in norms:
+        m.momentum = 1.0
+    with torch.no_grad():
+        y_train = s.netG1(x)
+    set_norm_mode(s.netG1, "fix_norms")
     before = [m.running_mean.clone() for m in norms]
     y = s.netG1(x)
     y.float().pow(2).mean().backward()
     assert all(torch.equal(m.running_mean, b0) for m, b0 in zip(norms, before))       # eval mode does not update them
+    assert float((y - y_train).abs().max()) <= 3e-2 * float(y_train.abs().max())
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0

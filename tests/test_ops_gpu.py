@@ -514,7 +514,7 @@ def test_instance_norm_running_stats_matches_torch(nd):
         yr.backward(go); y.backward(go.to(dev))
         assert relerr(y, yr) <= TOL and relerr(xd.grad, xr.grad) <= 2 * TOL
     assert relerr(mine.running_mean, ref.running_mean) <= 1e-2 and relerr(mine.running_var, ref.running_var) <= 1e-2
-    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
     mine.eval(); ref.eval()
     ref.running_mean.copy_(mine.running_mean.cpu()); ref.running_var.copy_(mine.running_var.cpu())
     x0 = rnd(shape, 80, -2, 3)
