@@ -308,6 +308,8 @@ int rg_igemm4_tile_n(int cout) { return ig4_fn(round_up(cout, 16) / 16); }
 
 bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
+bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
+int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat) {
   Igemm4Args a;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
@@ -339,6 +341,7 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
       RG_FAIL(RG_ERR_UNSUPPORTED, "conv: tap displacement beyond 511 voxels along dim %d", d);
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
+  if (flat && rg_halo16_ok(X, Y, p) && !getenv("RG_NO_HALO")) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
   if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !getenv("RG_NO_THIN")) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;
   const int fn = flat ? (nf <= 6 ? nf : (nf == 7 ? 8 : ig4_fn(nf))) : ig4_fn(nf);

@@ -523,3 +523,32 @@ def test_instance_norm_running_stats_matches_torch(nd):
     go = rnd(shape, 81)
     yr.backward(go); y.backward(go.to(dev))
     assert relerr(y, yr) <= TOL and relerr(xd.grad, xr.grad) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,pad,act", [(12, 12, (36, 40, 44), 0, "relu"), (16, 9, (33, 35, 70), 1, "sigmoid"), (10, 16, (40, 37, 41), 0, "none")])
+def test_halo16_thin_conv_forward_and_backward_data(cin, cout, sp, pad, act, monkeypatch):
+    """conv5.hip halo16_kernel (input halo tile in LDS, weights in registers: the 12 -> 12 U-Net levels) — forward, fused bias /
+    activation, zero padding, ragged tile edges and the backward-data pass (flipped taps) against torch fp32 on the CPU, and
+    identical to the persistent thin kernel it replaces (RG_NO_HALO=1)."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((2, cin) + sp, 51); w0 = rnd((cout, cin, 3, 3, 3), 52, -0.2, 0.2); b0 = rnd((cout,), 53)
+    afn = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid}[act]
+    xr = x0.clone().requires_grad_()
+    yr = afn(F.conv3d(xr, w0, b0, padding=pad))
+    go = rnd(tuple(yr.shape), 54)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    outs = {}
+    for flag in ("", "1"):
+        if flag:
+            monkeypatch.setenv("RG_NO_HALO", "1")
+        xd = x0.clone().to(dev).requires_grad_()
+        y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, pad, act)
+        name = _lib.lib().rg_last_kernel_name().decode()
+        assert ("halo16" in name) == (flag == ""), name
+        (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+        assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL
+        assert float(y[:, cout:].abs().max()) == 0 if y.shape[1] > cout else True
+        outs[flag] = (y.float().cpu(), gx.float().cpu())
+    assert relerr(outs[""][0], outs["1"][0]) <= 2 ** -7 and relerr(outs[""][1], outs["1"][1]) <= 2 ** -7
