@@ -46,13 +46,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 #endif
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
-  switch (act) {
-    case RG_ACT_RELU: return v > 0.f ? v : 0.f;
-    case RG_ACT_LEAKY: return v > 0.f ? v : v * slope;
-    case RG_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    case RG_ACT_TANH: return tanhf(v);
-    default: return v;
+  // none / ReLU / LeakyReLU without a branch (epilogues call this per element inside unrolled loops: the scalar branches of a
+  // switch cost more than a thin layer's MFMAs, see conv5.hip); the two transcendental ones behind one wave-uniform branch
+  if (act <= RG_ACT_LEAKY) {
+    const float neg = act == RG_ACT_RELU ? 0.f : v * (act == RG_ACT_LEAKY ? slope : 1.f);
+    return v > 0.f ? v : neg;
   }
+  return act == RG_ACT_SIGMOID ? 1.f / (1.f + __expf(-v)) : tanhf(v);
 }
 // derivative expressed through the OUTPUT y of the activation
 __device__ __forceinline__ float act_bwd_from_y(float y, int act, float slope) {
