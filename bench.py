@@ -231,6 +231,7 @@ def main_aux(a, rank, local, world, dev):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    noise_case = None
     if a.workload == "segment":  # the library bracketed the persistent Kruskal kernel of every call
         buf = (C.c_float * (a.steps + 1))()
         n = _lib.lib().rg_profile_drain(buf, a.steps + 1)
@@ -238,6 +239,18 @@ def main_aux(a, rank, local, world, dev):
         ops.profile_stop()
         if int(out.view(-1)[0].item()) == -1:
             raise RuntimeError("mutex watershed made no progress")
+        if a.affs == "blobs":  # the adversarial input beside the structured one: pure noise = one giant cluster, ~1100 rounds
+            structured = affs
+            affs = torch.rand(structured.shape, generator=torch.Generator(device=dev).manual_seed(5 + rank), device=dev)
+            step(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                nout = step()
+            torch.cuda.synchronize()
+            nms = (time.perf_counter() - t1) / 3 * 1e3
+            noise_case = dict(workload="pure-noise 20-channel affinities (adversarial: one giant cluster)", ms_per_step=round(nms, 3),
+                              value=round(units / (nms * 1e-3) / 1e6, 1), unit="Mvoxels/s", segments=int(nout.max().item()))
+            affs = structured
     else:
         prof = ops.profile_stop()
     if world > 1:
@@ -263,6 +276,8 @@ def main_aux(a, rank, local, world, dev):
                                         if a.affs == "blobs" else "pure-noise 20-channel affinities (adversarial: one giant cluster), ") +
                                         "segment.py:188-199 pipeline, labels left in HBM", parallelism=f"replicas x{world}"),
                    segments=int(out.max().item()))
+        if noise_case is not None:
+            res["noise_case"] = noise_case
     else:
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
