@@ -99,6 +99,13 @@ typedef struct {
 } rg_conv_params;
 int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                     const rg_conv_params* p, rg_stream s);
+/* The same with a caller-owned workspace: launches whose tile grid would leave most CUs idle (few output rows, long K: the
+ * backward-data pass of the 432 <- 2592 layer at 21^3, the PatchGAN's 15^3 layers) split K over up to 8 workgroups per tile, fp32
+ * partial sums go through the workspace and a second pass applies bias + activation.  rg_conv3d_igemm_workspace_bytes returns an
+ * upper bound (0: never splits); a NULL / too small workspace simply runs unsplit. */
+int64_t rg_conv3d_igemm_workspace_bytes(const rg_tensor* x, const rg_tensor* y, const rg_conv_params* p);
+int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
+                     const rg_conv_params* p, void* workspace, size_t ws_bytes, rg_stream s);
 
 /* ---- weight gradient.  dW[a][b][tap] = sum_rows g[row][a] * x[row*rstride + tbase + tstep*tap][b]
  * (torch's conv backward-weight for the layers above).  Two steps: partial sums over row splits into the

@@ -17,7 +17,8 @@ int rg_launch_igemm3(const CL5& X, const CL5& Y, const void* w_packed, const flo
 bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
 bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p);
 int rg_igemm4_tile_n(int cout);
-int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat);
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
+                     void* workspace, size_t ws_bytes);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
 static const void* zero_page() {
   static const void* cache[64] = {nullptr};
@@ -29,6 +30,20 @@ static const void* zero_page() {
 
 extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                                const rg_conv_params* p, rg_stream s) {
+  return rg_conv3d_igemm2(x, w_packed, bias, y, p, nullptr, 0, s);
+}
+// Upper bound of what rg_conv3d_igemm2 can use: split-K partial sums, fp32 [<= 8 splits][rows][output lanes], for launches whose
+// tile grid would leave most of the chip idle (few rows, long K).  0 when the problem is large enough never to split.
+extern "C" int64_t rg_conv3d_igemm_workspace_bytes(const rg_tensor* x, const rg_tensor* y, const rg_conv_params* p) {
+  CL5 X, Y;
+  if (rg_as_cl5(x, &X, "conv.x") || rg_as_cl5(y, &Y, "conv.y") || !p) return -1;
+  const long M = (long)X.N * p->R[0] * p->R[1] * p->R[2];
+  const long tiles64 = ((M + 63) / 64) * ((Y.lanes + 143) / 144);   // the smallest tile the engine uses
+  if (tiles64 > 1024 || Y.lanes < 64) return 0;                      // cannot be at most half a round of any tile shape / thin kernels
+  return (int64_t)8 * M * Y.lanes * 4;
+}
+extern "C" int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
+                                const rg_conv_params* p, void* workspace, size_t ws_bytes, rg_stream s) {
   CL5 X, Y;
   int rc;
   if ((rc = rg_as_cl5(x, &X, "conv.x")) || (rc = rg_as_cl5(y, &Y, "conv.y"))) return rc;
@@ -47,14 +62,14 @@ extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const f
     // igemm4 (activations straight into fragments) for 128/144-channel tiles; the kw-reuse kernel keeps the unpadded
     // 128-channel stride-1 layers (787 vs 731 TFLOP/s) and both LDS kernels the narrow tiles
     const bool i3 = rg_igemm3_ok(X, p);
-    if (rg_igemm4_ok(X, p) && !(i3 && rg_igemm4_tile_n(p->cout) == 8)) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0))) return rc; }
+    if (rg_igemm4_ok(X, p) && !(i3 && rg_igemm4_tile_n(p->cout) == 8)) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0, workspace, ws_bytes))) return rc; }
     else if (i3) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     else rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     RG_CHECK_LAUNCH();
     return RG_OK;
   }
   if (rg_conv3d_kalign(X.C, p->cout) == 1) {  // K flattened across taps, activations straight into fragments
-    if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 1))) return rc;
+    if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 1, workspace, ws_bytes))) return rc;
     RG_CHECK_LAUNCH();
     return RG_OK;
   }

@@ -37,6 +37,7 @@ struct Igemm4Args {
   int tiles_m, tiles_n;
   unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
   int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
+  int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
 };
 
 typedef __attribute__((address_space(3))) void* lptr4_t;
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   extern __shared__ PieceInfo ptab[];  // FLAT only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = a.tiles_m * a.tiles_n;
+  const int nwg = a.tiles_m * a.tiles_n * a.ksplit;
   int bid = blockIdx.x;
   { const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+  const int split = bid / (a.tiles_m * a.tiles_n); bid -= split * (a.tiles_m * a.tiles_n);
   const int tile_n = bid / a.tiles_m, tile_m = bid % a.tiles_m;
   const long m0 = (long)tile_m * BM;
   const int n0 = tile_n * BN;
@@ -96,9 +98,12 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     wv[i] = v ? (unsigned)(((long)n * (FLAT ? a.krow : ntaps * a.cink) + slot * 8) * 2) : IG4_OOB;
   }
   const int nchunk = a.cink >> 6;
-  const int nk = FLAT ? a.krow >> 6 : ntaps * nchunk;
+  // K range of this workgroup in K-steps (non-FLAT: step = chunk * ntaps + tap): everything, or the split's share
+  const int kunits = FLAT ? a.krow >> 6 : nchunk * ntaps, kper = (kunits + a.ksplit - 1) / a.ksplit;
+  const int ku0 = split * kper, ku1 = ku0 + kper < kunits ? ku0 + kper : kunits;
+  const int nk = ku1 > ku0 ? ku1 - ku0 : 0;
   if (FLAT) {
-    for (int P = tid; P < nk * 8; P += 256) {
+    for (int P = tid; P < (a.krow >> 6) * 8; P += 256) {
       const int tap = P / a.cp, c8 = P - tap * a.cp;
       PieceInfo e; e.off = 0; e.disp = -1;
       if (tap < ntaps) {
@@ -116,9 +121,11 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
 
   // ---- producer odometers (the K-step whose loads are issued next): channel chunk OUTER, tap INNER.  The weights run
   // two steps ahead (registers, then LDS), the activation fragments one (registers only)
-  int pchunk = 0, kd = 0, kh = 0, kw = 0;  // activations
-  int btap = 0, bchunk = 0;                // weights
-  int astep = 0, bstep = 0;                // FLAT: plain K-step counters
+  int pchunk = ku0 / ntaps, kd, kh, kw;                    // activations: (chunk, tap) of the first step
+  { const int t0 = ku0 - pchunk * ntaps; kw = t0 % a.TW; kh = (t0 / a.TW) % a.TH; kd = t0 / (a.TW * a.TH); }
+  int btap = ku0 - pchunk * ntaps, bchunk = pchunk;        // weights
+  int astep = ku0, bstep = ku0;                            // FLAT: plain K-step counters
+  int bleft = nk;                                          // non-FLAT: weight steps still to load
   auto advance_a = [&]() {
     ++kw;
     const int cw = kw == a.TW; kw = cw ? 0 : kw; kh += cw;
@@ -128,7 +135,8 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   auto advance_b = [&]() { ++btap; const int c = btap == ntaps; btap = c ? 0 : btap; bchunk += c; };
   u32x4_t sb[BPW];  // one stage of weights in flight through the registers
   auto load_b = [&]() {
-    const bool ok = FLAT ? bstep < nk : bchunk < nchunk;
+    const bool ok = FLAT ? bstep < ku1 : bleft > 0;
+    --bleft;
     const int so = ok ? (FLAT ? bstep * 128 : (btap * a.cink + bchunk * 64) * 2) : 0;
 #pragma unroll
     for (int i = 0; i < BPW; ++i) sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw_, (int)(ok ? wv[i] : IG4_OOB), so, 0);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     if constexpr (FLAT) {
       PieceInfo e0, e1;
       e0.off = 0; e0.disp = -1; e1 = e0;
-      if (astep < nk) { e0 = ptab[astep * 8 + fg]; e1 = ptab[astep * 8 + 4 + fg]; }
+      if (astep < ku1) { e0 = ptab[astep * 8 + fg]; e1 = ptab[astep * 8 + 4 + fg]; }
       ++astep;
       const int d0 = (e0.disp & 1023) - 512, h0 = ((e0.disp >> 10) & 1023) - 512, w0 = ((e0.disp >> 20) & 1023) - 512;
       const int d1 = (e1.disp & 1023) - 512, h1 = ((e1.disp >> 10) & 1023) - 512, w1 = ((e1.disp >> 20) & 1023) - 512;
@@ -236,6 +244,20 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   }
 
   // ---- epilogue: lane holds channels c..c+3 of voxel (lane&15) for every fragment
+  if (a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the bf16 store happen in igemm4_combine_kernel
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const long m = m0 + wave * (16 * FM) + i * 16 + fr;
+      if (m >= a.M) continue;
+      float* prow = a.part + ((long)split * a.M + m) * a.cout_lanes;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = n0 + j * 16 + fg * 4;
+        if (c < a.cout_lanes) *(f32x4*)(prow + c) = acc[i][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const long m = m0 + wave * (16 * FM) + i * 16 + fr;
@@ -265,13 +287,54 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   }
 }
 
+// y[row][c] = act(sum_s part[s][row][c] + bias[c]) for a split-K launch: one thread per (row, 4 channels), splits summed in order
+__global__ __launch_bounds__(256) void igemm4_combine_kernel(Igemm4Args a) {
+  const int q4 = a.cout_lanes >> 2;
+  const long total = a.M * q4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / q4; const int c = (int)(i - m * q4) * 4;
+    f32x4 v = *(const f32x4*)(a.part + m * a.cout_lanes + c);
+    for (int sp = 1; sp < a.ksplit; ++sp) {
+      const f32x4 u = *(const f32x4*)(a.part + ((long)sp * a.M + m) * a.cout_lanes + c);
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    long t = m;
+    const int rw = (int)(t % a.RW); t /= a.RW;
+    const int rh = (int)(t % a.RH); t /= a.RH;
+    const int rd = (int)(t % a.RD); t /= a.RD;
+    bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+                   (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = 0.f;
+      if (c + r < a.cout) x = act_fwd(v[r] + (a.bias ? a.bias[c + r] : 0.f), a.act, a.slope);
+      o[r] = (short)f2bf(x);
+    }
+    *(bf16x4*)(yrow + c) = o;
+  }
+}
+// Split count for a grid of `tiles` workgroups on `slots` co-resident ones: split K when at most half the slots are used and
+// the K range is long enough (>= 4 units per split); never beyond what the caller's workspace holds
+static int ig4_ksplit(long tiles, long slots, int kunits) {
+  if (tiles * 2 > slots || kunits < 16) return 1;
+  long s = slots / tiles; if (s > 8) s = 8; if (s > kunits / 8) s = kunits / 8;
+  return s < 2 ? 1 : (int)s;
+}
+
 template <int FM, int FN>
-static void launch_igemm4(Igemm4Args& a, bool check, bool flat, hipStream_t s) {
+static void launch_igemm4(Igemm4Args& a, bool check, bool flat, hipStream_t s, float* ws, size_t ws_bytes) {
   constexpr int BM = 64 * FM, BN = FN * 16;
   a.tiles_m = (int)((a.M + BM - 1) / BM);
   a.tiles_n = (a.cout_lanes + BN - 1) / BN;
-  rg_set_kernel_name("igemm4_kernel<%d,%d,%d%s>", FM, FN, (int)check, flat ? ",flat" : "");
-  const dim3 grid(a.tiles_m * a.tiles_n);
+  a.ksplit = 1; a.part = nullptr;
+  {
+    const long slots = FM >= 3 ? 512 : (FM == 2 ? 768 : 1024);
+    const int ks = ig4_ksplit((long)a.tiles_m * a.tiles_n, slots, flat ? a.krow >> 6 : (a.cink >> 6) * a.TD * a.TH * a.TW);
+    if (ks > 1 && ws && (size_t)ks * a.M * a.cout_lanes * 4 <= ws_bytes && (a.cout_lanes & 3) == 0) { a.ksplit = ks; a.part = ws; }
+  }
+  rg_set_kernel_name("igemm4_kernel<%d,%d,%d%s>%s", FM, FN, (int)check, flat ? ",flat" : "", a.ksplit > 1 ? "+splitK" : "");
+  const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
   if (flat) {
     const size_t shm = (size_t)(a.krow / 8) * sizeof(PieceInfo);
     if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true, true>), grid, dim3(256), shm, s, a);
@@ -281,6 +344,10 @@ static void launch_igemm4(Igemm4Args& a, bool check, bool flat, hipStream_t s) {
       if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true, false>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((igemm4_kernel<FM, FN, false, false>), grid, dim3(256), 0, s, a);
     }
+  }
+  if (a.ksplit > 1) {
+    long blocks = (a.M * (a.cout_lanes >> 2) + 255) / 256; if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(igemm4_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
   }
 }
 
@@ -310,7 +377,8 @@ bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
 int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
-int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat) {
+int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
+                     void* workspace, size_t ws_bytes) {
   Igemm4Args a;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
@@ -363,8 +431,9 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   }
   // small grids (PatchGAN's 15^3/16^3 layers, the parity classes of the transposed convs): 64-row tiles so that more CUs get a tile
   if (!e && fm == 2 && b2 < 192) fm = 1;
-#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st); else if (fm == 3 && (FN_ == 9 || FN_ == 8)) launch_igemm4<3, (FN_ == 8 ? 8 : 9)>(a, check, flat != 0, st); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st); \
-                        else launch_igemm4<2, FN_>(a, check, flat != 0, st); } while (0)
+  float* wsf = (float*)workspace;
+#define RG_L4(FN_) do { if (fm == 4) launch_igemm4<4, FN_>(a, check, flat != 0, st, wsf, ws_bytes); else if (fm == 3 && (FN_ == 9 || FN_ == 8)) launch_igemm4<3, (FN_ == 8 ? 8 : 9)>(a, check, flat != 0, st, wsf, ws_bytes); else if (fm == 1) launch_igemm4<1, FN_>(a, check, flat != 0, st, wsf, ws_bytes); \
+                        else launch_igemm4<2, FN_>(a, check, flat != 0, st, wsf, ws_bytes); } while (0)
   switch (fn) {
     case 1: RG_L4(1); break;
     case 2: RG_L4(2); break;

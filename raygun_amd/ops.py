@@ -369,9 +369,12 @@ def _conv_flops(p, n, cin, cout):
 def _igemm(x, wp, bias, y, p):
     bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
     dx, dy = desc(x), desc(y)
+    nbytes = _L().rg_conv3d_igemm_workspace_bytes(C.byref(dx), C.byref(dy), C.byref(p))   # split-K partial sums of small-grid launches
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes > 0 else None
     _timed(_conv_flops(p, x.shape[0], x.shape[1], y.shape[1]),
-           lambda: _lib.check(_L().rg_conv3d_igemm(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
-                                                         _stream()), "rg_conv3d_igemm"),
+           lambda: _lib.check(_L().rg_conv3d_igemm2(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
+                                                    C.c_void_p(ws.data_ptr()) if ws is not None else None, max(nbytes, 0), _stream()),
+                              "rg_conv3d_igemm"),
            lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} R{tuple(p.R)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)}")
 
 

@@ -552,3 +552,25 @@ def test_halo16_thin_conv_forward_and_backward_data(cin, cout, sp, pad, act, mon
         assert float(y[:, cout:].abs().max()) == 0 if y.shape[1] > cout else True
         outs[flag] = (y.float().cpu(), gx.float().cpu())
     assert relerr(outs[""][0], outs["1"][0]) <= 2 ** -7 and relerr(outs[""][1], outs["1"][1]) <= 2 ** -7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,pad,act", [(512, 144, (6, 6, 6), 0, "relu"), (256, 130, (5, 6, 7), 1, "none"), (72, 80, (8, 8, 9), 0, "leaky"),
+                                                 (448, 136, (7, 7, 7), 1, "sigmoid")])
+def test_split_k_small_grid_convolutions(cin, cout, sp, pad, act):
+    """Launches whose tile grid fills at most half the chip split K over several workgroups per tile (igemm4 "+splitK": fp32 partial
+    sums through the caller's workspace, bias / activation in the combine pass) — forward and backward-data against torch fp32 on
+    the CPU, for channel-chunked and FLAT packings, ragged channel counts and zero padding."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((1, cin) + sp, 61); w0 = rnd((cout, cin, 3, 3, 3), 62, -0.05, 0.05); b0 = rnd((cout,), 63)
+    afn = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    xr = x0.clone().requires_grad_()
+    yr = afn(F.conv3d(xr, w0, b0, padding=pad))
+    go = rnd(tuple(yr.shape), 64)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    xd = x0.clone().to(dev).requires_grad_()
+    y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, pad, act, 0.2)
+    assert "+splitK" in _lib.lib().rg_last_kernel_name().decode(), _lib.lib().rg_last_kernel_name().decode()
+    (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+    assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL
