@@ -23,6 +23,7 @@ __device__ __forceinline__ void s4_impl(F&& f, std::integer_sequence<int, Is...>
 template <int N, class F>
 __device__ __forceinline__ void s4for(F&& f) { s4_impl(f, std::make_integer_sequence<int, N>{}); }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 struct Igemm4Args {
   const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
   int N, ID, IH, IW;
@@ -41,12 +42,31 @@ struct Igemm4Args {
 };
 
 typedef __attribute__((address_space(3))) void* lptr4_t;
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ void ld4_16(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
 template <int N>
 __device__ __forceinline__ void ld4_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 #define IG4_OOB 0x80000000u
+// Buffer loads hipcc does not count.  Its own bookkeeping merges the prologue's state into the loop header and ends up with
+// s_waitcnt vmcnt(0) right after every step's barrier: the k-half 1 fragments issued at the end of a step were waited for
+// at once.  The loads below are retired by hand-counted waits (vmcnt completes in issue order) that name the registers.
+typedef int i32x4_t4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t4 ig4_rsrc(const void* base, unsigned nrec) {
+  const unsigned long b = (unsigned long)base;
+  return (i32x4_t4){(int)(unsigned)b, (int)((b >> 32) & 0xffffu), (int)nrec, 0x00020000};
+}
+__device__ __forceinline__ void ig4_load(u32x4_t& dst, i32x4_t4 rsrc, unsigned voff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void ig4_load_s(u32x4_t& dst, i32x4_t4 rsrc, unsigned voff, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ig4_vmwait(u32x4_t& first) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(first) : "n"(N) : "memory"); }
+__device__ __forceinline__ void ig4_tie(u32x4_t& r) { asm volatile("" : "+v"(r)); }
+#ifndef IG4_NS
+#define IG4_NS 1   // activation register sets for tiles of <= 192 rows; 2 (loads 1.5 steps ahead) measured no faster on MI355X
+#endif
 
 // FLAT: K is walked in 8-lane pieces ACROSS taps (K = taps*lanes padded once to 64, not per tap): channel counts that are
 // not multiples of 64 (12, 72, 84 ... lanes) waste no MFMA work.  A 64-wide K-step then mixes taps, so each lane looks its
@@ -116,8 +136,7 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     }
     __syncthreads();
   }
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)a.xbytes, 0x00020000);
-  const auto rw_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, (int)a.wbytes, 0x00020000);
+  const i32x4_t4 rx = ig4_rsrc(a.x, a.xbytes), rw_ = ig4_rsrc(a.w, a.wbytes);
 
   // ---- producer odometers (the K-step whose loads are issued next): channel chunk OUTER, tap INNER.  The weights run
   // two steps ahead (registers, then LDS), the activation fragments one (registers only)
@@ -139,13 +158,14 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     --bleft;
     const int so = ok ? (FLAT ? bstep * 128 : (btap * a.cink + bchunk * 64) * 2) : 0;
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) sb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw_, (int)(ok ? wv[i] : IG4_OOB), so, 0);
+    for (int i = 0; i < BPW; ++i) ig4_load_s(sb[i], rw_, ok ? wv[i] : IG4_OOB, so);
     if (FLAT) ++bstep; else advance_b();
   };
   // activation fragments live in ONE register set: the k-half 0 pieces of step ks+1 are loaded once the k-half 0
   // MFMAs of step ks have issued (mid-step), the k-half 1 pieces at the end of the step — half a step of latency cover
   // each (>= 288 MFMA cycles per wave, times the waves sharing the SIMD) for half the registers of a double buffer
-  u32x4_t xa[FM][2];
+  constexpr int NS = FM <= 3 ? IG4_NS : 1;  // activation register sets: loads run NS - 1/2 steps ahead of their MFMAs
+  u32x4_t xa[NS][FM][2];
   unsigned vo0[FM], vo1[FM];
   auto prep_a = [&]() {
     if constexpr (FLAT) {
@@ -181,13 +201,21 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     advance_a();
     }
   };
-  auto load_a0 = [&]() {
+  auto load_a0 = [&](auto S) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) xa[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo0[i], 0, 0);
+    for (int i = 0; i < FM; ++i) ig4_load(xa[decltype(S)::value][i][0], rx, vo0[i]);
   };
-  auto load_a1 = [&]() {
+  auto load_a1 = [&](auto S) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) xa[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)vo1[i], 0, 0);
+    for (int i = 0; i < FM; ++i) ig4_load(xa[decltype(S)::value][i][1], rx, vo1[i]);
+  };
+  // vector-memory operations per step, in issue order: BPW weight pieces (top), FM k-half-0 fragments (mid-step), FM k-half-1
+  // fragments (end); WAIT_B / WAIT_A = how many YOUNGER ones are in flight when the weight set / a fragment half is needed
+  constexpr int WAIT_B = 2 * FM, WAIT_A = FM + BPW + (NS - 1) * (BPW + 2 * FM);
+  static_assert(WAIT_A < 64 && NS <= 2, "vmcnt is a 6-bit counter; the prologue below orders its loads for NS <= 2");
+  auto tie_b = [&]() {
+#pragma unroll
+    for (int i = 1; i < BPW; ++i) ig4_tie(sb[i]);
   };
   auto store_b = [&](int buf) {
     bf16_t* Bs = lds + buf * BSTAGE + lane * 8;
@@ -202,18 +230,23 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // prologue: stage 0 weights -> LDS buffer 0, stage 1 weights in registers; activations of stage 0 in flight
-  load_b(); prep_a(); load_a0(); load_a1();
+  // (same issue order as the loop: the weight set of step 0 is followed by exactly 2*FM younger loads)
+  load_b();
+  if constexpr (NS == 2) { prep_a(); load_a0(std::integral_constant<int, 0>{}); load_a1(std::integral_constant<int, 0>{}); }
+  ig4_vmwait<2 * FM * (NS - 1)>(sb[0]); tie_b();
   store_b(0);
   load_b();
+  { prep_a(); load_a0(std::integral_constant<int, NS - 1>{}); load_a1(std::integral_constant<int, NS - 1>{}); }
 
   const unsigned lds0 = (unsigned)(size_t)(lptr4_t)lds;
   const unsigned b_lane = lds0 + fr * 128 + ((fg ^ fsw) << 4);
   constexpr int T2 = 2 * FN;
   int stage = 0;
-  for (int ks = 0; ks < nk; ++ks) {
+  auto step = [&](auto S) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my weight stores of this stage (issued last step) are done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    ig4_vmwait<WAIT_B>(sb[0]); tie_b();
     store_b(stage ^ 1);           // weights of step ks+1: registers -> the buffer whose readers finished before the barrier
     load_b();                     // weights of step ks+2 -> registers
     // no wait for the ds_writes above: LDS operations of a wave complete in order, so the counted waits below (which
@@ -231,18 +264,37 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
       }
       constexpr int NW = (t + 1 < T2) + (t + 2 < T2);
       ld4_wait<NW>(wf[t % 3]);
+      if constexpr (j == 0) {   // this k-half's fragments have landed
+        ig4_vmwait<WAIT_A>(xa[decltype(S)::value][0][kk]);
+#pragma unroll
+        for (int i = 1; i < FM; ++i) ig4_tie(xa[decltype(S)::value][i][kk]);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         bf16x8 xf;
-        __builtin_memcpy(&xf, &xa[i][kk], 16);
+        __builtin_memcpy(&xf, &xa[decltype(S)::value][i][kk], 16);
         acc[i][j] = RG_MFMA16(wf[t % 3], xf, acc[i][j]);
       }
-      if constexpr (t == FN - 1) { prep_a(); load_a0(); }  // k-half 0 fragments are free: fetch those of step ks+1
+      if constexpr (t == FN - 1) { prep_a(); load_a0(S); }  // k-half 0 fragments are free: fetch those of step ks+NS
     });
-    load_a1();
+    load_a1(S);
     stage ^= 1;
+  };
+  if constexpr (NS == 1) {
+    for (int ks = 0; ks < nk; ++ks) step(std::integral_constant<int, 0>{});
+  } else {
+    for (int ks = 0; ks < nk; ks += 2) {
+      step(std::integral_constant<int, 0>{});
+      if (ks + 1 < nk) step(std::integral_constant<int, 1>{});
+    }
   }
 
+  // the loads issued past the end of K still target xa / sb: retire them before the registers are reused
+  ig4_vmwait<0>(sb[0]); tie_b();
+  s4for<NS>([&](auto S) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) { ig4_tie(xa[decltype(S)::value][i][0]); ig4_tie(xa[decltype(S)::value][i][1]); }
+  });
   // ---- epilogue: lane holds channels c..c+3 of voxel (lane&15) for every fragment
   if (a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the bf16 store happen in igemm4_combine_kernel
 #pragma unroll

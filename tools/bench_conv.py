@@ -1,6 +1,8 @@
 import sys, time, torch, ctypes as C
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raygun_amd import ops, _lib
+sfx=os.environ.get('RG_LIB_SUFFIX')
+if sfx: _lib.LIB_PATHS['bf16']=_lib.LIB_PATH.replace('.so', sfx+'.so')
 dev=torch.device('cuda')
 shapes=[ # cin,cout,in_spatial,k
  (3024,432,34,3),(2592,2592,19,3),(432,432,44,3),(432,2592,21,3),(504,72,60,3),(72,72,94,3),(432,432,32,3),(72,432,46,3),
