@@ -931,13 +931,26 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   if (const int kind = wgrad_kw_kind(G, X, p, *fa, *fb, &kg)) {  // wgrad_kw_kernel: split over 32-row units
     const long units = kg.units;
     const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
-    // workgroups aimed at: three rounds of one workgroup per CU.  Measured on the U-Net step (whole step, so the partial-sum
-    // traffic and the reduction passes behind the kernel count): 1536 -> 29.96 ms, 1024 -> 29.68, 768 -> 29.37, 512 -> 29.46, 384 -> 30.55
-    (void)kind;
-    const long target = 768;
-    // the targets are whole rounds of co-resident workgroups: round the split count DOWN so that the grid never spills a few
-    // workgroups into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815)
-    long ns = target / tl; if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
+    // workgroups aimed at: whole rounds of co-resident workgroups, rounded DOWN so that the grid never spills a few workgroups
+    // into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815).
+    // Kernels with several workgroups per CU: 768 (measured on the whole U-Net step, so that the partial-sum traffic and the
+    // reduction passes count: 1536 -> 29.96 ms, 1024 -> 29.68, 768 -> 29.37, 512 -> 29.46; 256 starves the thin tiles: 29.1 vs 27.8).
+    long ns = 768 / tl;
+    if ((kind == 1 || kind == 3) && p->T[2] <= 3) {
+      // producer-wave kernels, ONE workgroup per CU: 1, 2 or 3 rounds by a cost model — a round costs its units (~0.9 us each)
+      // plus ~6 us of prologue / epilogue, every split writes and re-reads one fp32 copy of the gradient tile set (~3.5 TB/s
+      // each way).  CycleGAN's 128 -> 128 ResNet-block layers at 32^3 (9 tiles, 1024 units, 1.8 MB of gradient): 85 splits
+      // = 150 MB of partial sums, 148 us per call; 28 splits = one round: the step 96.4 -> 94.0 ms.
+      const double out_mb = (double)(*fa * 16) * (*fb * 16) * p->T[2] * 4.0 * tl / 1e6;
+      double best = 1e30;
+      for (int r = 1; r <= 3; ++r) {
+        long n = (long)r * 256 / tl; if (n > units / 16) n = units / 16; if (n < 1) n = 1;
+        const long u = (units + n - 1) / n, n2 = (units + u - 1) / u;
+        const double cost = (double)((tl * n2 + 255) / 256) * (u * 0.9 + 6.0) + (n2 > 1 ? n2 * out_mb * 2.0 / 3.5 : 0.0);
+        if (cost < best) { best = cost; ns = n; }
+      }
+    }
+    if (ns > units / 16) ns = units / 16; if (ns < 1) ns = 1;
     const long ups = (units + ns - 1) / ns;
     *nsplit = (int)((units + ups - 1) / ups);
     *rows_per_split = ups;
