@@ -107,6 +107,26 @@ int64_t rg_conv3d_igemm_workspace_bytes(const rg_tensor* x, const rg_tensor* y, 
 int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                      const rg_conv_params* p, void* workspace, size_t ws_bytes, rg_stream s);
 
+/* ---- Winograd F(2x2x2, 3x3x3) path for wide stride-1 3x3x3 convolutions (same torch.nn.Conv3d call sites as above, networks/UNet.py:58-69:
+ * config U's 2592 -> 2592 level).  y = A^T [ sum_c U(k,c) . V(c) ] A per 2x2x2 output tile; the 64 transform positions are 64
+ * independent GEMMs.  Layouts (16-bit storage type of this build):
+ *   V, M  [64][tiles][row stride]      tiles = N * tiles[0] * tiles[1] * tiles[2], tile t covers outputs 2t .. 2t+1 per axis
+ *   U     [64][rg_wino_weights_rows(cout)][rg_wino_weights_red(cin)]   forward operand (rows = output channels)
+ *   Ut    [64][rg_wino_weights_rows(cin)][rg_wino_weights_red(cout)]   backward-data operand (the flipped kernel: positions mirrored)
+ * rg_wino_input reads x at origin + 2*tile + (0..3) per axis, zeros outside the tensor (origin 0: valid convolution; -2: the
+ * full correlation of the backward-data pass) and zero-fills the lanes up to v_cstride.  rg_wino_output adds the bias, applies
+ * the activation and crops the last odd tile.  rg_gemm_batched: C[b][m][n] = sum_k A[b][m][k] * W[b][n][k] on the
+ * fragment-direct implicit-GEMM kernel, fp32 accumulation; n must tile by 128 or 144 columns, A's lanes k .. round_up(k, 64)
+ * must hold zeros (rg_wino_input writes them). */
+int64_t rg_wino_weights_rows(int32_t channels);
+int64_t rg_wino_weights_red(int32_t channels);
+int rg_wino_weights(const void* w_f32, int32_t channels_last, int32_t cout, int32_t cin, void* U, void* Ut, rg_stream s);
+int rg_wino_input(const rg_tensor* x, void* V, int64_t v_cstride, const int32_t tiles[3], const int32_t origin[3], rg_stream s);
+int rg_wino_output(const void* M, int64_t m_cstride, const int32_t tiles[3], rg_tensor* y, const float* bias, int32_t cout,
+                   int32_t act, float slope, rg_stream s);
+int rg_gemm_batched(const void* A, const void* W, void* C, int64_t batches, int64_t m, int32_t k, int32_t n, int64_t a_row_stride,
+                    int64_t a_batch_stride, int64_t w_batch_stride, int64_t c_row_stride, int64_t c_batch_stride, rg_stream s);
+
 /* ---- weight gradient.  dW[a][b][tap] = sum_rows g[row][a] * x[row*rstride + tbase + tstep*tap][b]
  * (torch's conv backward-weight for the layers above).  Two steps: partial sums over row splits into the
  * caller's fp32 workspace, then a deterministic reduction that also transposes into torch's (a,b,KD,KH,KW) layout.

@@ -51,6 +51,13 @@ _SIGS = {
     "rg_conv3d_igemm": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p]),
     "rg_conv3d_igemm_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params)]),
     "rg_conv3d_igemm2": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_wino_weights_rows": (C.c_int64, [C.c_int32]),
+    "rg_wino_weights_red": (C.c_int64, [C.c_int32]),
+    "rg_wino_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rg_wino_input": (C.c_int, [_T, C.c_void_p, C.c_int64, _I3, _I3, C.c_void_p]),
+    "rg_wino_output": (C.c_int, [C.c_void_p, C.c_int64, _I3, _T, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "rg_gemm_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "rg_conv3d_wgrad_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params), _P(C.c_int32)]),
     "rg_conv3d_wgrad2": (C.c_int, [_T, _T, C.c_void_p, _P(rg_conv_params), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_conv3d_wgrad": (C.c_int, [_T, _T, C.c_void_p, _P(rg_conv_params), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

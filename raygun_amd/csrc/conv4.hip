@@ -39,6 +39,7 @@ struct Igemm4Args {
   unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
   int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
   int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
+  int nbatch; long xbatch, wbatch, ybatch;  // batched GEMM (rg_gemm_batched): element strides between the problems; no split-K
 };
 
 typedef __attribute__((address_space(3))) void* lptr4_t;
@@ -81,9 +82,13 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   extern __shared__ PieceInfo ptab[];  // FLAT only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwg = a.tiles_m * a.tiles_n * a.ksplit;
+  const int nwg = a.tiles_m * a.tiles_n * a.ksplit * a.nbatch;
   int bid = blockIdx.x;
   { const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+  const int batch = bid / (a.tiles_m * a.tiles_n * a.ksplit); bid -= batch * (a.tiles_m * a.tiles_n * a.ksplit);
+  const bf16_t* const xbase = a.x + batch * a.xbatch;
+  const bf16_t* const wbase = a.w + batch * a.wbatch;
+  bf16_t* const ybase = a.y + batch * a.ybatch;
   const int split = bid / (a.tiles_m * a.tiles_n); bid -= split * (a.tiles_m * a.tiles_n);
   const int tile_n = bid / a.tiles_m, tile_m = bid % a.tiles_m;
   const long m0 = (long)tile_m * BM;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     }
     __syncthreads();
   }
-  const i32x4_t4 rx = ig4_rsrc(a.x, a.xbytes), rw_ = ig4_rsrc(a.w, a.wbytes);
+  const i32x4_t4 rx = ig4_rsrc(xbase, a.xbytes), rw_ = ig4_rsrc(wbase, a.wbytes);
 
   // ---- producer odometers (the K-step whose loads are issued next): channel chunk OUTER, tap INNER.  The weights run
   // two steps ahead (registers, then LDS), the activation fragments one (registers only)
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     const int rw = (int)(t % a.RW); t /= a.RW;
     const int rh = (int)(t % a.RH); t /= a.RH;
     const int rd = (int)(t % a.RD); t /= a.RD;
-    bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+    bf16_t* yrow = ybase + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
                    (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -383,10 +388,10 @@ static void launch_igemm4(Igemm4Args& a, bool check, bool flat, hipStream_t s, f
   {
     const long slots = FM >= 3 ? 512 : (FM == 2 ? 768 : 1024);
     const int ks = ig4_ksplit((long)a.tiles_m * a.tiles_n, slots, flat ? a.krow >> 6 : (a.cink >> 6) * a.TD * a.TH * a.TW);
-    if (ks > 1 && ws && (size_t)ks * a.M * a.cout_lanes * 4 <= ws_bytes && (a.cout_lanes & 3) == 0) { a.ksplit = ks; a.part = ws; }
+    if (ks > 1 && a.nbatch == 1 && ws && (size_t)ks * a.M * a.cout_lanes * 4 <= ws_bytes && (a.cout_lanes & 3) == 0) { a.ksplit = ks; a.part = ws; }
   }
   rg_set_kernel_name("igemm4_kernel<%d,%d,%d%s>%s", FM, FN, (int)check, flat ? ",flat" : "", a.ksplit > 1 ? "+splitK" : "");
-  const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
+  const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit * a.nbatch);
   if (flat) {
     const size_t shm = (size_t)(a.krow / 8) * sizeof(PieceInfo);
     if (check) hipLaunchKernelGGL((igemm4_kernel<FM, FN, true, true>), grid, dim3(256), shm, s, a);
@@ -429,9 +434,17 @@ bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
 int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
+struct Igemm4Batch { int n; long xs, ws, ys; };
+static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
+                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt);
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                      void* workspace, size_t ws_bytes) {
+  return launch_igemm4_any(X, Y, w_packed, bias, p, st, flat, workspace, ws_bytes, nullptr);
+}
+static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
+                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt) {
   Igemm4Args a;
+  a.nbatch = bt ? bt->n : 1; a.xbatch = bt ? bt->xs : 0; a.wbatch = bt ? bt->ws : 0; a.ybatch = bt ? bt->ys : 0;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
   a.RD = p->R[0]; a.RH = p->R[1]; a.RW = p->R[2];
@@ -461,6 +474,7 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
       RG_FAIL(RG_ERR_UNSUPPORTED, "conv: tap displacement beyond 511 voxels along dim %d", d);
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
+  if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
   if (flat && rg_halo16_ok(X, Y, p) && !getenv("RG_NO_HALO")) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
   if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !getenv("RG_NO_THIN")) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;
@@ -469,7 +483,7 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   // TFLOP/s when the grid fills the chip) or 128 (FM = 2, three per CU, ~820-900).  Few-tile problems lose whole CUs to
   // the coarser grid, so estimate both from the measured rates and the fill of the last round of workgroups
   const int ntn = (nf + fn - 1) / fn;
-  const long b2 = ((a.M + 127) / 128) * ntn, b4 = ((a.M + 255) / 256) * ntn;
+  const long b2 = ((a.M + 127) / 128) * ntn * a.nbatch, b4 = ((a.M + 255) / 256) * ntn * a.nbatch;
   const double e2 = b2 <= 768 ? b2 / 768.0 : 0.5 + 0.5 * b2 / (double)((b2 + 767) / 768 * 768);  // co-resident workgroups speed up when a CU is not full
   const double e4 = b4 <= 512 ? b4 / 512.0 : b4 / (double)((b4 + 511) / 512 * 512);
   const char* e = getenv("RG_FM");
@@ -477,7 +491,7 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
   // 192-row tiles (FM = 3, 144-channel tiles only) for grids that leave the last round of 256- and 128-row tiles half empty
   // (2592 -> 2592 at 17^3: 360 / 468 / 702 tiles -> 821 TFLOP/s with FM = 2, 887 with FM = 3); never for grids below one tile per CU
   if (!e && (fn == 9 || fn == 8) && a.rs[0] == 1 && a.rs[1] == 1 && a.rs[2] == 1) {  // (strided gathers measured slower with 192 rows)
-    const long b3 = ((a.M + 191) / 192) * ntn;
+    const long b3 = ((a.M + 191) / 192) * ntn * a.nbatch;
     const double e3 = b3 <= 512 ? b3 / 512.0 : b3 / (double)((b3 + 511) / 512 * 512);
     if (b3 >= 256 && 950.0 * e3 > 1.03 * (fm == 4 ? 1030.0 * e4 : 880.0 * e2)) fm = 3;
   }
@@ -497,6 +511,28 @@ int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const flo
     default: RG_L4(9); break;
   }
   return RG_OK;
+}
+
+// C[b][m][n] = sum_k A[b][m][k] * W[b][n][k]: `batches` independent GEMMs on the fragment-direct kernel (one launch; the
+// transform-domain products of the Winograd path, winograd.hip).  A rows are a_rs elements apart (lanes past k must hold zeros up
+// to the next multiple of 64, like W's rows), C rows c_rs; 16-bit storage type of this build, fp32 accumulation.
+extern "C" int rg_gemm_batched(const void* A, const void* W, void* Cm, int64_t batches, int64_t m, int32_t k, int32_t n, int64_t a_rs,
+                               int64_t a_bs, int64_t w_bs, int64_t c_rs, int64_t c_bs, rg_stream stream) {
+  if (!A || !W || !Cm || batches <= 0 || m <= 0 || k <= 0 || n <= 0) RG_FAIL(RG_ERR_BAD_SHAPE, "gemm_batched: null pointer or empty problem");
+  const int kp = round_up(k, 64);
+  if (a_rs < kp || (a_rs & 7) || c_rs < round_up(n, 8) || (c_rs & 7) || m >= (1L << 31) || batches >= (1 << 16))
+    RG_FAIL(RG_ERR_BAD_SHAPE, "gemm_batched: row strides must cover k rounded up to 64 / n rounded up to 8 and be multiples of 8");
+  CL5 X, Y;
+  X.p = (bf16_t*)A; X.N = 1; X.C = k; X.D = 1; X.H = 1; X.W = (int)m; X.lanes = kp; X.sn = m * a_rs; X.sd = m * a_rs; X.sh = m * a_rs; X.sw = a_rs;
+  Y.p = (bf16_t*)Cm; Y.N = 1; Y.C = n; Y.D = 1; Y.H = 1; Y.W = (int)m; Y.lanes = round_up(n, 8); Y.sn = m * c_rs; Y.sd = m * c_rs; Y.sh = m * c_rs; Y.sw = c_rs;
+  rg_conv_params p;
+  memset(&p, 0, sizeof(p));
+  p.R[0] = 1; p.R[1] = 1; p.R[2] = (int)m;
+  for (int d = 0; d < 3; ++d) { p.T[d] = 1; p.rstride[d] = 1; p.tstep[d] = 1; p.ostride[d] = 1; }
+  p.cout = n; p.act = RG_ACT_NONE;
+  if (ig4_fn(round_up(n, 16) / 16) < 8) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: n = %d has no 128/144-column tiling", n);
+  Igemm4Batch bt; bt.n = (int)batches; bt.xs = a_bs; bt.ws = w_bs; bt.ys = c_bs;
+  return launch_igemm4_any(X, Y, W, nullptr, &p, (hipStream_t)stream, 0, nullptr, 0, &bt);
 }
 
 // ---- thin outputs (Cout <= 16): weights resident in LDS ----------------------------------------------------------------

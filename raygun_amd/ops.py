@@ -348,14 +348,14 @@ def profile_stop():
 profile_shapes = False  # True: key the records by kernel name AND problem shape (diagnostics)
 
 
-def _timed(flops, fn, tag=None, marked=False):
+def _timed(flops, fn, tag=None, marked=False, name=None):
     if _prof is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    name = _L().rg_last_kernel_name().decode()
+    name = name() if name is not None else _L().rg_last_kernel_name().decode()
     if profile_shapes and tag is not None:
         name += " " + tag()
     _prof.append((name, flops, e0, e1, marked))
@@ -376,6 +376,71 @@ def _igemm(x, wp, bias, y, p):
                                                     C.c_void_p(ws.data_ptr()) if ws is not None else None, max(nbytes, 0), _stream()),
                               "rg_conv3d_igemm"),
            lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} R{tuple(p.R)} T{tuple(p.T)} rs{tuple(p.rstride)} ts{tuple(p.tstep)}")
+
+
+WINO_MIN_CHANNELS = 1024  # Winograd F(2,3)^3 only where K = Cin is long (config U's 2592 -> 2592 level); see csrc/winograd.hip
+
+
+def _wino_ok(weight, stride, padding, dw_swapped):
+    """Winograd path for this convolution?  bf16 storage only: the transform-domain rounding doubles that layer's error, which
+    the 1e-3 budget of the f16 block runner does not have."""
+    return (os.environ.get("RAYGUN_AMD_WINOGRAD", "1") != "0" and not dw_swapped and storage_dtype() == torch.bfloat16
+            and tuple(weight.shape[2:]) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (0, 0, 0)
+            and weight.shape[0] >= WINO_MIN_CHANNELS and weight.shape[1] >= WINO_MIN_CHANNELS and weight.dtype == torch.float32
+            and (is_cl_weight(weight) or weight.is_contiguous()))
+
+
+def _wino_weights(weight):
+    """(U, Ut): G g G^T of the fp32 master weight as the forward and the backward-data GEMM operand; cached like the packed
+    operands (per tensor version, dropped by FusedAdam / invalidate_packed)."""
+    cache = getattr(weight, "_rg_pack_cache", None)
+    ver = (weight._version, weight.data_ptr())
+    if cache is None or cache.get("ver") != ver:
+        cache = {"ver": ver}
+        try:
+            weight._rg_pack_cache = cache
+        except Exception:
+            pass
+    if "wino" in cache:
+        return cache["wino"]
+    L = _L()
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    wd = weight.detach()
+    U = torch.empty(64 * L.rg_wino_weights_rows(cout) * L.rg_wino_weights_red(cin), dtype=torch.bfloat16, device=weight.device)
+    Ut = torch.empty(64 * L.rg_wino_weights_rows(cin) * L.rg_wino_weights_red(cout), dtype=torch.bfloat16, device=weight.device)
+    _lib.check(L.rg_wino_weights(C.c_void_p(wd.data_ptr()), int(is_cl_weight(wd)), cout, cin, C.c_void_p(U.data_ptr()),
+                                 C.c_void_p(Ut.data_ptr()), _stream()), "rg_wino_weights")
+    cache["wino"] = (U, Ut)
+    return U, Ut
+
+
+def _wino_conv(x, Wt, bias, act, slope, y, origin):
+    """y = conv(x, w) through the transform domain.  x (N, k, ...) and y (N, n, ...) channels-last; Wt the matching operand of
+    _wino_weights; origin 0: valid convolution, -2: full correlation with the flipped kernel (backward-data)."""
+    L = _L()
+    n_, k = int(x.shape[0]), int(x.shape[1])
+    nout = int(y.shape[1])
+    tiles = [(int(o) + 1) // 2 for o in y.shape[2:]]
+    nt = n_ * tiles[0] * tiles[1] * tiles[2]
+    cs, ms = int(L.rg_wino_weights_red(k)), int(L.rg_wino_weights_red(nout))
+    V = torch.empty(64 * nt * cs, dtype=torch.bfloat16, device=x.device)
+    M = torch.empty(64 * nt * ms, dtype=torch.bfloat16, device=x.device)
+    dx, dy = desc(x), desc(y)
+    bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
+
+    def run():
+        _lib.check(L.rg_wino_input(C.byref(dx), C.c_void_p(V.data_ptr()), cs, _lib.i3(tiles), _lib.i3([origin] * 3), _stream()), "rg_wino_input")
+        _lib.check(L.rg_gemm_batched(C.c_void_p(V.data_ptr()), C.c_void_p(Wt.data_ptr()), C.c_void_p(M.data_ptr()), 64, nt, k, nout, cs,
+                                     nt * cs, int(L.rg_wino_weights_rows(nout)) * cs, ms, nt * ms, _stream()), "rg_gemm_batched")
+        gname = L.rg_last_kernel_name().decode()
+        _lib.check(L.rg_wino_output(C.c_void_p(M.data_ptr()), ms, _lib.i3(tiles), C.byref(dy), bptr, nout, ACT[act], float(slope), _stream()),
+                   "rg_wino_output")
+        return gname
+
+    names = []
+    o = [int(v) for v in y.shape[2:]]
+    _timed(2.0 * n_ * o[0] * o[1] * o[2] * 27 * k * nout, lambda: names.append(run()),
+           lambda: f"x{tuple(x.shape)} -> y{tuple(y.shape)} origin {origin}", name=lambda: "winograd[" + names[-1] + "]")
 
 
 def _wgrad(g, x, p, shape, channels_last=False):
@@ -548,11 +613,15 @@ class _Conv3d(Function):
             raise RuntimeError(f"Calculated padded input size per channel: {tuple(i + 2 * p for i, p in zip((D, H, W), padding))}. "
                                f"Kernel size: {K}. Kernel size can't be greater than actual input size")
         y = alloc(n, cout, *O, x.device)
-        wp = pack_weights(weight, swap=0)
         b = bias.detach().float().contiguous() if bias is not None else None
-        p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
-                         ooffset=(0, 0, 0), cout=cout, act=act, slope=slope)
-        _igemm(x, wp, b, y, p)
+        ctx.wino = _wino_ok(weight, stride, padding, dw_swapped)
+        if ctx.wino:
+            _wino_conv(x, _wino_weights(weight)[0], b, act, slope, y, 0)
+        else:
+            wp = pack_weights(weight, swap=0)
+            p = _conv_params(R=O, T=K, rstride=stride, tbase=[-q for q in padding], tstep=(1, 1, 1), ostride=(1, 1, 1),
+                             ooffset=(0, 0, 0), cout=cout, act=act, slope=slope)
+            _igemm(x, wp, b, y, p)
         ctx.save_for_backward(x, weight, y if act != "none" else None)
         ctx.cfg = (stride, padding, act, slope, bias is not None, K, O)
         return y
@@ -567,7 +636,9 @@ class _Conv3d(Function):
         n, cin, D, H, W = x.shape
         if ctx.needs_input_grad[0]:
             gx = ctx.alloc(n, cin, D, H, W, x.device)
-            if stride == (1, 1, 1):
+            if ctx.wino:
+                _wino_conv(g, _wino_weights(weight)[1], None, "none", 0.0, gx, -2)
+            elif stride == (1, 1, 1):
                 wp = pack_weights(weight, swap=1)
                 p = _conv_params(R=(D, H, W), T=K, rstride=(1, 1, 1), tbase=padding, tstep=(-1, -1, -1),
                                  ostride=(1, 1, 1), ooffset=(0, 0, 0), cout=cin)
