@@ -146,8 +146,8 @@ struct WinoW {
   bf16_t* Ut; int trows, tred;       // Ut[64][trows][tred]: rows = cin, contiguous = cout; position index mirrored (0 <-> 3 per axis)
 };
 
-// One (k, c) per thread, 32 x 32 tile per 1024-thread workgroup: U rows are written straight from the registers (c contiguous
-// across the wave), the transposed operand goes through a 16-position LDS slab so that its rows are written k-contiguous too.
+// One (k, c) per thread, 32 x 32 tile per 1024-thread workgroup; both operands leave through a 16-position LDS slab so that
+// their rows are written in 16-byte pieces (U: c-contiguous, Ut: k-contiguous).
 __global__ __launch_bounds__(1024) void wino_w_kernel(WinoW a) {
   constexpr int LS = 40;  // LDS row length (elements): 80 B rows keep the 16-byte reads aligned and spread the 2-byte writes
   __shared__ __attribute__((aligned(16))) bf16_t lt[16 * 32 * LS];
@@ -170,17 +170,24 @@ __global__ __launch_bounds__(1024) void wino_w_kernel(WinoW a) {
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) WINO_G(u[0][j][kk], u[1][j][kk], u[2][j][kk], u[3][j][kk], u2[0][j][kk], u2[1][j][kk], u2[2][j][kk]);
-  const bool wu = k < a.urows && c < a.ured;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // forward operand
-    if (wu) {
+    // forward operand: slab of the 16 positions (i, *, *) as [pos][k][c], written out in 16-byte pieces of 8 c
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a.U[((long)((i * 4 + j) * 4 + kk) * a.urows + k) * a.ured + c] = f2bf(u[i][j][kk]);
+      for (int kk = 0; kk < 4; ++kk) lt[((j * 4 + kk) * 32 + kl) * LS + cl] = f2bf(u[i][j][kk]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int item = tid + 1024 * q;            // 16 positions x 32 k x 4 pieces of 8 c
+      const int piece = item & 3, kr = (item >> 2) & 31, pp = item >> 7;
+      const int krow = blockIdx.y * 32 + kr, c0 = blockIdx.x * 32 + piece * 8;
+      if (krow < a.urows && c0 < a.ured)
+        *(bf16x8*)(a.U + ((long)(i * 16 + pp) * a.urows + krow) * a.ured + c0) = *(const bf16x8*)(lt + (pp * 32 + kr) * LS + piece * 8);
     }
-    // transposed operand: slab of the 16 positions (i, *, *)
+    // transposed operand: the same slab as [pos][c][k], position index mirrored
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
