@@ -459,6 +459,146 @@ static bool wgrad_line_ok(const CL5& G, const CL5& X, const rg_conv_params* p, i
   return p->T[2] <= WL_MAXW;
 }
 
+// ---- thin layers, blocks of lines (3x3xTW valid convolutions of <= 16 lanes on both sides) ------------------------------------
+// wgrad_line_kernel stages the nine (kd,kh) input lines of every output line: the input is read 9 times through L1/L2
+// (12 -> 12 at 192^3: 2.3 GB per launch, 0.33 ms against a 0.09-ms HBM floor).  Here a unit is a block of LD x LH output lines
+// (same 32-voxel chunk along W): the (LD+2) x (LH+2) input lines it needs are staged ONCE — 3 input lines per output line instead
+// of 9 — and every (line, tap) pair is one MFMA on fragments read with the transposing LDS reads at line / row offsets.
+// Lines past the end of D or H and rows past the end of a line are masked in the G tile (zeros), the input lines they would
+// have needed are read from wherever the offsets fall inside the tensor (finite) or beyond it (zeros).
+#define WB_LD 2
+#define WB_LH 4
+struct WgradLinesArgs { WgradArgs w; long units; long units_per_split; int wchunks, dgroups, hgroups; unsigned xbytes, gbytes; };
+__global__ __launch_bounds__(256) void wgrad_lines_kernel(WgradLinesArgs p) {
+  const WgradArgs& a = p.w;
+  constexpr int LD = WB_LD, LH = WB_LH, GL = LD * LH, XH = LH + 2, XL = (LD + 2) * XH, XR = 34;
+  constexpr int STAGE = (GL * 32 + XL * XR) * 16;  // bf16 elements per LDS stage (34 KB)
+  extern __shared__ __attribute__((aligned(16))) bf16_t wl_lds[];
+  bf16_t* lds = wl_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntaps = 9 * a.TW;
+  const long ubeg = (long)blockIdx.z * p.units_per_split;
+  long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
+  constexpr int NACC = 7;  // taps wave, wave + 4, ... of at most 27
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  typedef __attribute__((address_space(3))) bf16x4 lds_b64;
+  const int gsw2 = (int)a.gsw * 2, xsw2 = (int)a.xsw * 2;
+  // per-thread piece list, fixed for the whole kernel: G pieces (line, row, half) first, then X pieces
+  constexpr int NG = GL * 64, NP = NG + XL * XR * 2, NLD = (NP + 255) / 256;
+  unsigned pv[NLD]; int pl[NLD]; int pm[NLD];  // byte offset from the unit's base, LDS element offset (-1: none), G mask key
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int q = tid + 256 * k;
+    pv[k] = WG_OOB; pl[k] = -1; pm[k] = -1;
+    if (q < NG) {
+      const int l = q >> 6, rr = (q >> 1) & 31, cc = (q & 1) * 8, ld = l / LH, lh = l % LH;
+      pl[k] = (l * 32 + rr) * 16 + cc;
+      pm[k] = ld | (lh << 8) | (rr << 16);
+      if (cc < a.alanes) pv[k] = (unsigned)((int)(ld * a.gsd + lh * a.gsh) * 2 + rr * gsw2 + cc * 2);
+    } else if (q < NP) {
+      const int q2 = q - NG, cc = (q2 & 1) * 8, rr = (q2 >> 1) % XR, xl = (q2 >> 1) / XR, xd = xl / XH, xh = xl % XH;
+      pl[k] = (GL * 32 + xl * XR + rr) * 16 + cc;
+      if (cc < a.blanes) pv[k] = (unsigned)((int)(xd * a.xsd + xh * a.xsh) * 2 + rr * xsw2 + cc * 2);
+    }
+  }
+  int xfo[NACC];  // LDS element offset of tap (wave + 4 i)'s fragment rows relative to an output line's first input line, -1: no tap
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int tl = wave + 4 * i;
+    const int kw = tl % a.TW, kh = (tl / a.TW) % 3, kd = tl / (3 * a.TW);
+    xfo[i] = tl < ntaps ? (GL * 32 + (kd * XH + kh) * XR + kw + 8 * fg + fq) * 16 + 4 * fp : -1;
+  }
+  int cwc, chg, cdg, cn;
+  {
+    unsigned t = (unsigned)ubeg;
+    cwc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
+    chg = (int)(t % (unsigned)p.hgroups); t /= (unsigned)p.hgroups;
+    cdg = (int)(t % (unsigned)p.dgroups); cn = (int)(t / (unsigned)p.dgroups);
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, (int)p.xbytes, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, (short)0, (int)p.gbytes, 0x00020000);
+  u32x4 regs[NLD];
+  auto gload = [&]() {  // loads the unit under the cursor, then advances the cursor
+    const int w0 = cwc * 32, d0 = cdg * LD, h0 = chg * LH;
+    const int nld = a.RD - d0, nlh = a.RH - h0, nrw = a.RW - w0;  // valid lines / rows of this unit (may exceed the block)
+    const int gadd = (int)(cn * a.gsn + (long)d0 * a.gsd + (long)h0 * a.gsh + (long)w0 * a.gsw) * 2;
+    const int xadd = (int)(cn * a.xsn + (long)(d0 + a.tb[0]) * a.xsd + (long)(h0 + a.tb[1]) * a.xsh + (long)(w0 + a.tb[2]) * a.xsw) * 2;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      if ((k + 1) * 256 <= NG) {          // G pieces only
+        const bool ok = (pm[k] & 255) < nld && ((pm[k] >> 8) & 255) < nlh && (pm[k] >> 16) < nrw;
+        regs[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(ok ? pv[k] + (unsigned)gadd : WG_OOB), 0, 0);
+      } else if (k * 256 >= NG) {         // X pieces only
+        regs[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(pv[k] + (unsigned)xadd), 0, 0);
+      } else {                            // the straddling slot: per-thread choice
+        const bool isg = pm[k] >= 0;
+        const bool ok = (pm[k] & 255) < nld && ((pm[k] >> 8) & 255) < nlh && (pm[k] >> 16) < nrw;
+        const u32x4 vg = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)(isg && ok ? pv[k] + (unsigned)gadd : WG_OOB), 0, 0);
+        const u32x4 vx = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(isg ? WG_OOB : pv[k] + (unsigned)xadd), 0, 0);
+        regs[k] = isg ? vg : vx;
+      }
+    }
+    if (++cwc == p.wchunks) { cwc = 0; if (++chg == p.hgroups) { chg = 0; if (++cdg == p.dgroups) { cdg = 0; ++cn; } } }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) if (pl[k] >= 0) *(u32x4*)(lds + buf * STAGE + pl[k]) = regs[k];
+  };
+  auto compute = [&](int buf) {
+    const bf16_t* Gs = lds + buf * STAGE;
+#pragma unroll
+    for (int l = 0; l < GL; ++l) {
+      const bf16_t* gb = Gs + (l * 32 + 8 * fg + fq) * 16 + 4 * fp;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(gb + 4 * 16));
+      const bf16x8 gf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const int loff = ((l / LH) * XH + (l % LH)) * XR * 16;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        if (xfo[i] >= 0) {
+          const bf16_t* xb = Gs + xfo[i] + loff;
+          const bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb));
+          const bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(xb + 4 * 16));
+          const bf16x8 xf = (bf16x8){l2[0], l2[1], l2[2], l2[3], h2[0], h2[1], h2[2], h2[3]};
+          acc[i] = RG_MFMA16(gf, xf, acc[i]);
+        }
+      }
+    }
+  };
+  if (ubeg < uend) gload();
+  int buf = 0;
+  for (long u = ubeg; u < uend; ++u, buf ^= 1) {
+    lstore(buf);
+    __syncthreads();
+    if (u + 1 < uend) gload();
+    compute(buf);
+  }
+  float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
+  const int bb = lane & 15;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap >= ntaps) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int aa = fg * 4 + r;
+      if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[i][r];
+    }
+  }
+}
+static bool wgrad_lines_ok(const CL5& G, const CL5& X, const rg_conv_params* p, int fa, int fb) {
+  if (fa != 1 || fb != 1 || getenv("RG_NO_WLINES")) return false;
+  if (wg_extent(X) * 2 >= (1L << 30) || wg_extent(G) * 2 >= (1L << 30)) return false;  // 32-bit byte offsets
+  if (p->T[0] != 3 || p->T[1] != 3 || p->T[2] > 3) return false;
+  const int I[3] = {X.D, X.H, X.W};
+  for (int d = 0; d < 3; ++d)
+    if (p->rstride[d] != 1 || p->tstep[d] != 1 || p->tbase[d] < 0 || p->tbase[d] + p->T[d] - 1 + p->R[d] - 1 >= I[d]) return false;
+  return (long)G.N * p->R[0] * p->R[1] * p->R[2] >= (1L << 18);  // small problems: the per-line kernel has more units to spread
+}
+
 // ---- wide layers, line-aligned K-steps with kw reuse --------------------------------------------------------------
 // The flat kernel above is bound by the global->LDS path: a 144x144 tile moves 18.4 KB per 32-row step for ONE tap
 // (72 FLOP/B).  Here a K-step is 32 consecutive voxels of one output line and the workgroup owns ALL TW taps of one
@@ -956,6 +1096,14 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
     *rows_per_split = ups;
     return;
   }
+  if (wgrad_lines_ok(G, X, p, *fa, *fb)) {  // wgrad_lines_kernel: split over (block of lines, 32-voxel chunk) units
+    const long units = (long)G.N * ((p->R[0] + WB_LD - 1) / WB_LD) * ((p->R[1] + WB_LH - 1) / WB_LH) * ((p->R[2] + 31) / 32);
+    long ns = 1024; if (ns > units / 4) ns = units / 4; if (ns < 1) ns = 1;   // two workgroups per CU: two rounds
+    const long ups = (units + ns - 1) / ns;
+    *nsplit = (int)((units + ups - 1) / ups);
+    *rows_per_split = ups;
+    return;
+  }
   if (wgrad_line_ok(G, X, p, *fa, *fb)) {  // wgrad_line_kernel: split over (line, 32-voxel chunk) units
     const long wch = (p->R[2] + 31) / 32;
     const long units = (long)G.N * p->R[0] * p->R[1] * wch;
@@ -1110,6 +1258,17 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     else if (kind == 8) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 9) hipLaunchKernelGGL((wgrad_kw_kernel<8, 4, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
     else hipLaunchKernelGGL((wgrad_kw_kernel<4, 8, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
+  } else if (wgrad_lines_ok(G, X, p, fa, fb)) {
+    WgradLinesArgs la; la.w = a;
+    la.wchunks = (a.RW + 31) / 32; la.dgroups = (a.RD + WB_LD - 1) / WB_LD; la.hgroups = (a.RH + WB_LH - 1) / WB_LH;
+    la.units = (long)G.N * la.dgroups * la.hgroups * la.wchunks;
+    la.units_per_split = rps;
+    la.xbytes = (unsigned)(wg_extent(X) * 2); la.gbytes = (unsigned)(wg_extent(G) * 2);
+    constexpr size_t shm = 2 * (size_t)(WB_LD * WB_LH * 32 + (WB_LD + 2) * (WB_LH + 2) * 34) * 16 * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void*)wgrad_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+    rg_set_kernel_name("wgrad_lines_kernel");
+    hipLaunchKernelGGL(wgrad_lines_kernel, dim3(1, 1, ns), dim3(256), shm, st, la);
   } else if (wgrad_line_ok(G, X, p, fa, fb)) {
     WgradLineArgs la; la.w = a;
     la.wchunks = (a.RW + 31) / 32;

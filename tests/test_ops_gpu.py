@@ -616,3 +616,26 @@ def test_winograd_wide_conv_forward_and_backward(cin, cout, sp, act, cl, monkeyp
     monkeypatch.setenv("RAYGUN_AMD_WINOGRAD", "0")
     y2 = ops.conv3d(xd, wd, b0.to(dev), 1, 0, act, 0.2)
     assert relerr(y, y2) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp", [(12, 12, (67, 68, 69)), (1, 12, (66, 66, 66)), (10, 7, (66, 70, 66))])
+def test_thin_weight_gradient_blocks_of_lines(cin, cout, sp):
+    """wgrad_lines_kernel (<= 16 lanes on both sides, 3x3x3 valid, >= 2^18 output voxels: the 12 -> 12 levels and the folded 1 -> 12
+    stem): units of 2 x 4 output lines whose 4 x 6 input lines are staged once — extents that leave partial line blocks and a partial
+    32-voxel chunk, against torch fp32 on the CPU."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    x0 = rnd((1, cin) + sp, 81); w0 = rnd((cout, cin, 3, 3, 3), 82, -0.2, 0.2); b0 = rnd((cout,), 83)
+    xr = x0.clone().requires_grad_(cin > 1); wr = w0.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, b0)
+    go = rnd(tuple(yr.shape), 84)
+    (gwr,) = torch.autograd.grad(yr, (wr,), go)
+    xd = x0.clone().to(dev).requires_grad_(cin > 1)
+    wd = w0.clone().to(dev).requires_grad_()
+    ops.profile_start()
+    y = ops.conv3d(xd, wd, b0.to(dev), 1, 0, "none", 0.0)
+    (gw,) = torch.autograd.grad(y, (wd,), go.to(dev).to(y.dtype))
+    prof = ops.profile_stop()
+    assert any(n.startswith("wgrad_lines_kernel") for n in prof), list(prof)
+    assert relerr(gw, gwr) <= TOL, relerr(gw, gwr)
