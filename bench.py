@@ -218,9 +218,9 @@ def main_aux(a, rank, local, world, dev):
         nb = S.build_neighborhood()
         units = size ** 3
 
-        def step():
+        def step(stats=None):
             w, m = S.prepare_weights(affs, 3, 0.5, 1.0)
-            return S.compute_mws_segmentation(w, nb, 3, strides=[10, 10, 10], mask=m, as_tensor=True)
+            return S.compute_mws_segmentation(w, nb, 3, strides=[10, 10, 10], mask=m, as_tensor=True, stats=stats)
 
     for _ in range(a.warmup):
         out = step()
@@ -239,6 +239,8 @@ def main_aux(a, rank, local, world, dev):
         ops.profile_stop()
         if int(out.view(-1)[0].item()) == -1:
             raise RuntimeError("mutex watershed made no progress")
+        round_stats = {}
+        step(round_stats)  # one more, untimed call for the round kernel's own counters
         if a.affs == "blobs":  # the adversarial input beside the structured one: pure noise = one giant cluster, ~1100 rounds
             structured = affs
             affs = torch.rand(structured.shape, generator=torch.Generator(device=dev).manual_seed(5 + rank), device=dev)
@@ -248,8 +250,10 @@ def main_aux(a, rank, local, world, dev):
                 nout = step()
             torch.cuda.synchronize()
             nms = (time.perf_counter() - t1) / 3 * 1e3
+            nstats = {}
+            step(nstats)
             noise_case = dict(workload="pure-noise 20-channel affinities (adversarial: one giant cluster)", ms_per_step=round(nms, 3),
-                              value=round(units / (nms * 1e-3) / 1e6, 1), unit="Mvoxels/s", segments=int(nout.max().item()))
+                              value=round(units / (nms * 1e-3) / 1e6, 1), unit="Mvoxels/s", segments=int(nout.max().item()), round_kernel=nstats)
             affs = structured
     else:
         prof = ops.profile_stop()
@@ -276,6 +280,7 @@ def main_aux(a, rank, local, world, dev):
                                         if a.affs == "blobs" else "pure-noise 20-channel affinities (adversarial: one giant cluster), ") +
                                         "segment.py:188-199 pipeline, labels left in HBM", parallelism=f"replicas x{world}"),
                    segments=int(out.max().item()))
+        res["round_kernel"] = round_stats  # edges, rounds, window visits, ms in phase A / B / C (thread 0's clock, barriers included)
         if noise_case is not None:
             res["noise_case"] = noise_case
     else:

@@ -237,6 +237,9 @@ int64_t rg_mws_workspace_bytes(const rg_mws_params* p);
  * mask: uint8 (Z,Y,X) or NULL; labels: uint64 (Z,Y,X). */
 int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels,
                    const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s);
+/* Diagnostics of the last rg_mws_segment run that used `workspace`: out = {edges, rounds, window visits, 100-MHz ticks in phase
+ * A, B, C of the round kernel, mutex-list nodes, 0}.  Synchronises the stream. */
+int rg_mws_stats(const void* workspace, const rg_mws_params* p, uint64_t out[8], rg_stream s);
 /* segment.py:188-194 on the device (mask from the channel mean, weights = 1 - affs with the attractive channels flipped back),
  * rounded exactly as numpy does in float32.  affs / weights: (n_offsets, n_voxels) float32 (may not alias), mask: n_voxels bytes. */
 int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,

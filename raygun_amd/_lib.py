@@ -92,6 +92,7 @@ _SIGS = {
     "rg_mws_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "rg_mws_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
+    "rg_mws_stats": (C.c_int, [C.c_void_p, _P(rg_mws_params), C.c_void_p, C.c_void_p]),
     "rg_mws_cross_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, _P(rg_mws_params),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rg_mws_slab_mutexes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -102,7 +103,7 @@ _SIGS = {
 }
 
 DECLARED = sorted(_SIGS)
-_F16_ABSENT = {"rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_segment", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
+_F16_ABSENT = {"rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_segment", "rg_mws_stats", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
                "rg_mws_graph_workspace_bytes", "rg_mws_graph", "rg_mws_relabel"}  # no 16-bit data on the mutex-watershed path
 _libs = {}
 import threading

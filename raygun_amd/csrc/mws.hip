@@ -493,6 +493,20 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
   return RG_OK;
 }
 
+// Diagnostics of the last rg_mws_segment run in `workspace`: out = {edges, rounds, window visits, 100-MHz ticks spent in phase A, B, C
+// (thread 0's view, barriers included), mutex-list nodes used, 0}.  Synchronises the stream.
+extern "C" int rg_mws_stats(const void* workspace, const rg_mws_params* p, uint64_t out[8], rg_stream s) {
+  MwsPlan q;
+  if (!workspace || !out || mws_plan(p, &q)) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_stats: bad arguments");
+  const char* w = (const char*)workspace;
+  unsigned count = 0; MwsCtl ctl;
+  if (hipMemcpyAsync(&count, w + q.off_cnt, sizeof(count), hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess ||
+      hipMemcpyAsync(&ctl, w + q.off_cnt + 64, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)s) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)s) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_stats: copy failed");
+  out[0] = count; out[1] = ctl.rounds; out[2] = ctl.visits; out[3] = ctl.t[0]; out[4] = ctl.t[1]; out[5] = ctl.t[2]; out[6] = ctl.pool_used; out[7] = 0;
+  return RG_OK;
+}
+
 // ==== second level of the slab decomposition: mutex watershed of an explicit edge list ============
 // Nodes are first-level clusters, edges the grid edges that cross a slab boundary plus the mutexes the first level left between
 // clusters of one slab (wkey 0: before everything else).  Order: ascending wkey (= descending transformed weight, the same 32-bit

@@ -37,7 +37,7 @@ def build_neighborhood(neighborhood=None, n_diagonals=8):
 
 def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, strides=None, randomize_strides=False,
                              invert_repulsive_weights=True, bias_cut=0., mask=None, algorithm="kruskal", device=None,
-                             as_tensor=False, origin=(0, 0, 0)):
+                             as_tensor=False, origin=(0, 0, 0), stats=None):
     """GPU mutex watershed with affogato's call signature (affogato.segmentation.compute_mws_segmentation as published:
     weights, offsets, number_of_attractive_channels, strides=None, randomize_strides=False, invert_repulsive_weights=True,
     bias_cut=0., mask=None, algorithm='kruskal'; the reference's call site is segment.py:197-199).
@@ -91,6 +91,11 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
                                     C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
                                     C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment")
+        if stats is not None:  # diagnostics of the round kernel (synchronises)
+            buf = (C.c_uint64 * 8)()
+            _lib.check(L.rg_mws_stats(C.c_void_p(ws.data_ptr()), C.byref(p), buf, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_stats")
+            stats.update(edges=int(buf[0]), rounds=int(buf[1]), window_visits=int(buf[2]), phase_ms=[round(int(buf[3 + i]) / 1e5, 3) for i in range(3)],
+                         mutex_nodes=int(buf[6]))
     if as_tensor:
         return labels  # all-ones labels (= -1) would mean the device pass made no progress; callers that keep the tensor check
     out = labels.cpu().numpy().astype(np.uint64)
