@@ -265,6 +265,10 @@ int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uint32_t* eu, 
                  int64_t n_edges, int64_t n_nodes, int32_t* rep, void* workspace, size_t ws_bytes, rg_stream s);
 int rg_mws_relabel(int64_t* labels, const int64_t* lut, int64_t n, rg_stream s);
 
+/* ---- host-side codec for the chunk reader (no device work): one LZ4 block (the stream format inside zarr's default Blosc
+ * compressor) -> dst; returns the number of bytes written or -1 on malformed input / a too small buffer. */
+int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,7 @@ _SIGS = {
     "rg_profile_drain": (C.c_int, [C.c_void_p, C.c_int]),
     "rg_adam_step_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
+    "rg_lz4_decompress_block": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "rg_mws_workspace_bytes": (C.c_int64, [_P(rg_mws_params)]),
     "rg_mws_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "rg_mws_segment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p,

@@ -65,8 +65,11 @@ def test_gpu_labels_bit_exact(shape, strides, use_mask, structured):
         if structured and not inv:
             ww[3:] = 1 - ww[3:]      # the caller inverts instead
         ref = O.compute_mws_segmentation(ww, NB8, 3, strides, mask, invert_repulsive_weights=inv, bias_cut=bias)
-        got = compute_mws_segmentation(ww, NB8, 3, strides, mask=mask, invert_repulsive_weights=inv, bias_cut=bias)
+        st = {}
+        got = compute_mws_segmentation(ww, NB8, 3, strides, mask=mask, invert_repulsive_weights=inv, bias_cut=bias, stats=st)
         assert got.dtype == np.uint64 and got.shape == ref.shape
+        # rg_mws_stats: every edge enters the window at least once, in at least one round
+        assert st["rounds"] >= 1 and st["window_visits"] >= st["edges"] > 0 and len(st["phase_ms"]) == 3
         assert (got == ref).all(), f"invert={inv} bias={bias}: {int((got != ref).sum())} of {ref.size} labels differ"
         assert O.same_partition(got, ref)
     assert np.array_equal(w, keep)  # the caller's weights are not modified (affogato modifies them in place)
