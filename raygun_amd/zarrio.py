@@ -6,8 +6,15 @@ neither package is installed here, so this module restates the PUBLISHED zarr v2
 chunks = fill_value) — PARITY UNPINNED against the zarr package itself; `tests/test_zarrio.py` checks it against chunk files
 laid down by hand from the spec.
 
-Codecs: none, zlib, gzip, bz2, lzma (python stdlib).  Blosc — zarr's own default — needs numcodecs and raises a clear error.
-Filters are not supported.  N5 containers are not supported.
+Codecs: none, zlib, gzip, bz2, lzma (python stdlib), and READING of Blosc frames — zarr's own default compressor — with the lz4 /
+lz4hc / zlib inner codecs and byte- or bit-shuffle (`blosc_decode`, restated from the published c-blosc 1.x frame layout and the
+LZ4 block format; the LZ4 stream is decoded by the library's host-side `rg_lz4_decompress_block`, or by a slow pure-Python twin
+when the library is not built; blosclz / zstd / snappy inner codecs raise).  New arrays are written with zlib.  PARITY UNPINNED
+against numcodecs' Blosc as well: the tests decode frames laid down by hand from the format description.
+Filters are not supported.  N5 containers (the other format daisy.open_ds accepts) are READ through `N5Array`: attributes.json
+(dimensions / blockSize / dataType / compression, all in N5's fastest-axis-first order, reversed here), big-endian block files
+i0/i1/.. with the [mode, ndim, dims..] header, compression raw / gzip / bzip2 / xz / blosc; restated from the published N5 spec,
+unpinned like the rest.
 """
 import builtins
 import bz2
@@ -22,7 +29,114 @@ import numpy as np
 
 _fopen = builtins.open  # this module defines its own open() (zarr.open)
 
+def _lz4_block_py(src, out_len):
+    """LZ4 block -> bytes (pure Python twin of csrc/io.hip:rg_lz4_decompress_block)."""
+    src = memoryview(src)
+    n, ip, out = len(src), 0, bytearray()
+    while ip < n:
+        tok = src[ip]; ip += 1
+        lit = tok >> 4
+        if lit == 15:
+            while True:
+                b = src[ip]; ip += 1; lit += b
+                if b != 255:
+                    break
+        out += src[ip:ip + lit]; ip += lit
+        if ip >= n:
+            break
+        off = src[ip] | (src[ip + 1] << 8); ip += 2
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = src[ip]; ip += 1; ml += b
+                if b != 255:
+                    break
+        ml += 4
+        if off == 0 or off > len(out):
+            raise ValueError("blosc/lz4: bad match offset")
+        start = len(out) - off
+        if off >= ml:
+            out += out[start:start + ml]
+        else:  # overlapping match = a run of the last `off` bytes
+            pat = bytes(out[start:])
+            out += (pat * (ml // off + 1))[:ml]
+    if len(out) != out_len:
+        raise ValueError(f"blosc/lz4: block decoded to {len(out)} bytes, expected {out_len}")
+    return bytes(out)
+
+
+def _lz4_block(src, out_len):
+    try:
+        from . import _lib
+        L = _lib.lib()
+    except Exception:
+        return _lz4_block_py(src, out_len)
+    import ctypes as C
+    src = bytes(src)
+    dst = C.create_string_buffer(max(out_len, 1))
+    got = L.rg_lz4_decompress_block(src, len(src), dst, out_len)
+    if got != out_len:
+        raise ValueError(f"blosc/lz4: block decoded to {got} bytes, expected {out_len}")
+    return dst.raw[:out_len]
+
+
+def blosc_decode(buf):
+    """One Blosc (c-blosc 1.x) frame -> bytes.  Header: version, versionlz, flags, typesize, nbytes, blocksize, cbytes (u8 x4, u32 LE
+    x3); flags: 0x1 byte shuffle, 0x2 stored (memcpy), 0x4 bit shuffle, 0x10 blocks are not split, bits 5-7 inner codec (0 blosclz,
+    1 lz4 / lz4hc, 2 snappy, 3 zlib, 4 zstd).  Then one int32 start offset per block; a block is `typesize` streams (one per
+    byte position, when splitting applies: typesize <= 16, blocksize / typesize >= 128, not the short last block) or a single one,
+    each an int32 compressed size followed by the stream (size == uncompressed size: stored)."""
+    buf = memoryview(buf)
+    if len(buf) < 16:
+        raise ValueError("blosc: frame shorter than its header")
+    flags, typesize = buf[2], buf[3]
+    nbytes, blocksize, cbytes = (int.from_bytes(buf[4 + 4 * i:8 + 4 * i], "little") for i in range(3))
+    if cbytes > len(buf):
+        raise ValueError("blosc: truncated frame")
+    if flags & 0x2:
+        return bytes(buf[16:16 + nbytes])
+    codec = (flags >> 5) & 7
+    if codec not in (1, 3):
+        raise NotImplementedError("blosc: inner codec %s is not supported here (lz4, lz4hc and zlib are)" %
+                                  {0: "blosclz", 2: "snappy", 4: "zstd"}.get(codec, codec))
+    nblocks = (nbytes + blocksize - 1) // blocksize if nbytes else 0
+    out = bytearray()
+    for b in range(nblocks):
+        pos = int.from_bytes(buf[16 + 4 * b:20 + 4 * b], "little")
+        bsize = min(blocksize, nbytes - b * blocksize)
+        leftover = bsize != blocksize
+        nsplit = typesize if (not (flags & 0x10) and typesize <= 16 and blocksize // typesize >= 128 and not leftover) else 1
+        ne = bsize // nsplit
+        blk = bytearray()
+        for _ in range(nsplit):
+            cs = int.from_bytes(buf[pos:pos + 4], "little", signed=True); pos += 4
+            if cs < 0 or pos + cs > len(buf):
+                raise ValueError("blosc: bad stream size")
+            raw = buf[pos:pos + cs]; pos += cs
+            blk += raw if cs == ne else (_lz4_block(raw, ne) if codec == 1 else zlib.decompress(raw))
+        if len(blk) != bsize:
+            raise ValueError("blosc: block decoded to the wrong size")
+        if typesize > 1 and flags & 0x1:      # byte shuffle: byte k of every element is stored together
+            nel = bsize // typesize
+            a = np.frombuffer(blk, np.uint8)
+            body = a[:nel * typesize].reshape(typesize, nel).T.reshape(-1)
+            blk = body.tobytes() + bytes(a[nel * typesize:])
+        elif flags & 0x4:                     # bit shuffle: bit j of every element is stored together (multiples of 8 elements)
+            nel = (bsize // typesize) & ~7
+            a = np.frombuffer(blk, np.uint8)
+            bits = np.unpackbits(a[:nel * typesize].reshape(typesize * 8, nel // 8), axis=1, bitorder="little")
+            body = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)
+            blk = body.tobytes() + bytes(a[nel * typesize:])
+        out += blk
+    return bytes(out)
+
+
+def _no_blosc_write(b, cfg):
+    raise NotImplementedError("writing Blosc chunks is not supported: create the array with compressor zlib / gzip / none")
+
+
 _CODECS = {
+    "blosc": (_no_blosc_write, blosc_decode),
     "zlib": (lambda b, cfg: zlib.compress(b, cfg.get("level", 1)), lambda b: zlib.decompress(b)),
     "gzip": (lambda b, cfg: gzip.compress(b, cfg.get("level", 1)), lambda b: gzip.decompress(b)),
     "bz2": (lambda b, cfg: bz2.compress(b, cfg.get("level", 1)), lambda b: bz2.decompress(b)),
@@ -275,6 +389,67 @@ class Group:
         a[...] = value
 
 
+class N5Array(Array):
+    """Read-only view of one N5 dataset directory with numpy (slowest-axis-first) semantics."""
+
+    def __init__(self, path):
+        self.path, self.mode = path, "r"
+        with _fopen(os.path.join(path, "attributes.json")) as f:
+            m = json.load(f)
+        if "dimensions" not in m:
+            raise ValueError(f"{path}: attributes.json describes a group, not a dataset")
+        self.shape = tuple(int(v) for v in reversed(m["dimensions"]))
+        self.chunks = tuple(int(v) for v in reversed(m["blockSize"]))
+        self.dtype = np.dtype(m["dataType"]).newbyteorder(">")
+        self.order, self.fill_value, self.sep = "C", 0, "/"
+        comp = m.get("compression", {"type": m.get("compressionType", "raw")})
+        self.compressor = comp
+        dec = {"raw": lambda b: b, "gzip": gzip.decompress, "bzip2": bz2.decompress, "xz": lzma.decompress, "blosc": blosc_decode}
+        if comp.get("type") not in dec:
+            raise NotImplementedError(f"{path}: N5 compression {comp.get('type')!r} is not supported (raw, gzip, bzip2, xz, blosc are)")
+        self._decode = dec[comp["type"]]
+        self.attrs = Attributes(os.path.join(path, "attributes.json"), False)
+        self.ndim = len(self.shape)
+
+    def _chunk_path(self, idx):
+        return os.path.join(self.path, *[str(i) for i in reversed(idx)])
+
+    def _read_chunk(self, idx):
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            return None
+        with _fopen(p, "rb") as f:
+            raw = f.read()
+        mode, nd = int.from_bytes(raw[0:2], "big"), int.from_bytes(raw[2:4], "big")
+        dims = [int.from_bytes(raw[4 + 4 * i:8 + 4 * i], "big") for i in range(nd)]
+        pos = 4 + 4 * nd + (4 if mode == 1 else 0)
+        if mode not in (0, 1) or nd != self.ndim:
+            raise ValueError(f"{p}: unsupported N5 block header (mode {mode}, {nd} dims)")
+        a = np.frombuffer(self._decode(raw[pos:]), dtype=self.dtype)
+        shp = tuple(reversed(dims))
+        if a.size != int(np.prod(shp)):
+            raise ValueError(f"{p}: block holds {a.size} items, header says {shp}")
+        a = a.reshape(shp)
+        if shp != self.chunks:  # edge blocks are stored cropped
+            full = np.zeros(self.chunks, dtype=self.dtype)
+            full[tuple(slice(0, n) for n in shp)] = a
+            a = full
+        return a
+
+    def __getitem__(self, key):
+        return super().__getitem__(key).astype(self.dtype.newbyteorder("="), copy=False)
+
+    def __setitem__(self, key, value):
+        raise NotImplementedError("N5 containers are read-only here: write predictions to a zarr container")
+
+
+def _open_n5(path, ds_name=None):
+    full = os.path.join(path, ds_name) if ds_name else path
+    if not os.path.exists(os.path.join(full, "attributes.json")):
+        raise FileNotFoundError(os.path.join(full, "attributes.json"))
+    return N5Array(full)
+
+
 def open(path, mode="r"):  # noqa: A001  (mirrors zarr.open)
     """zarr.open(path, mode): a Group or an Array.  mode 'r' read-only, 'a' read/write (created when missing), 'w' recreate."""
     if mode == "w" and os.path.exists(path):
@@ -296,6 +471,12 @@ def open(path, mode="r"):  # noqa: A001  (mirrors zarr.open)
 def open_ds(filename, ds_name, mode="r"):
     """daisy.open_ds for zarr containers: the Array, with `.voxel_size` and `.offset` (world units) from its attributes
     ('resolution' / 'offset', defaults 1 and 0 per spatial axis)."""
+    if str(filename).rstrip("/").endswith(".n5"):  # daisy reverses N5's (x, y, z) attribute order as well
+        a = _open_n5(filename, ds_name)
+        nsp = min(3, a.ndim)
+        a.voxel_size = tuple(int(v) for v in reversed(a.attrs.get("resolution", (1,) * nsp)))
+        a.offset = tuple(int(v) for v in reversed(a.attrs.get("offset", (0,) * nsp)))
+        return a
     a = open(filename, mode)[ds_name]
     nsp = min(3, a.ndim)
     a.voxel_size = tuple(int(v) for v in a.attrs.get("resolution", (1,) * nsp))

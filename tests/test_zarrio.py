@@ -83,10 +83,116 @@ def test_unsupported_codec_is_loud(tmp_path):
     root = str(tmp_path / "b.zarr")
     _hand_made(root)
     meta = json.load(open(os.path.join(root, ".zarray")))
-    meta["compressor"] = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+    meta["compressor"] = {"id": "zstd", "level": 3}
     json.dump(meta, open(os.path.join(root, ".zarray"), "w"))
-    with pytest.raises(NotImplementedError, match="blosc"):
+    with pytest.raises(NotImplementedError, match="zstd"):
         zarrio.open(root)
+
+
+def _lz4_encode(data):
+    """A small greedy LZ4 block ENCODER written from the block format description (test-side only): 4-byte hash matches,
+    overlapping matches allowed, the last 5 bytes always literals (the format's end-of-block rule)."""
+    data = bytes(data); n = len(data); out = bytearray(); table = {}; i = anchor = 0
+
+    def emit(lit, mlen, off):
+        tok_l, tok_m = min(len(lit), 15), (min(mlen - 4, 15) if mlen else 0)
+        out.append((tok_l << 4) | tok_m)
+        if len(lit) >= 15:
+            r = len(lit) - 15
+            while r >= 255:
+                out.append(255); r -= 255
+            out.append(r)
+        out.extend(lit)
+        if mlen:
+            out.extend(off.to_bytes(2, "little"))
+            if mlen - 4 >= 15:
+                r = mlen - 4 - 15
+                while r >= 255:
+                    out.append(255); r -= 255
+                out.append(r)
+
+    while i + 4 <= n - 5:
+        key = data[i:i + 4]; cand = table.get(key); table[key] = i
+        if cand is not None and i - cand <= 65535:
+            m = 4
+            while i + m < n - 5 and data[cand + m] == data[i + m]:
+                m += 1
+            emit(data[anchor:i], m, i - cand)
+            i += m; anchor = i
+        else:
+            i += 1
+    emit(data[anchor:], 0, 0)
+    return bytes(out)
+
+
+def _blosc_frame(payload, typesize, blocksize, shuffle, codec="lz4", split=True):
+    """A c-blosc 1.x frame laid down by hand from the published layout (header, block starts, per-block split streams)."""
+    import zlib as _z
+    nbytes = len(payload)
+    flags = {"none": 0, "byte": 1, "bit": 4}[shuffle] | (0 if split else 0x10) | ({"lz4": 1, "zlib": 3}[codec] << 5)
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    blocks = []
+    for b in range(nblocks):
+        blk = np.frombuffer(payload[b * blocksize:(b + 1) * blocksize], np.uint8)
+        nel = len(blk) // typesize
+        if shuffle == "byte" and typesize > 1:
+            blk = np.concatenate([blk[:nel * typesize].reshape(nel, typesize).T.reshape(-1), blk[nel * typesize:]])
+        elif shuffle == "bit":
+            n8 = nel & ~7
+            bits = np.unpackbits(blk[:n8 * typesize].reshape(n8, typesize), axis=1, bitorder="little")   # [element][bit]
+            blk = np.concatenate([np.packbits(bits.T, axis=1, bitorder="little").reshape(-1), blk[n8 * typesize:]])
+        blk = blk.tobytes()
+        leftover = len(blk) != blocksize
+        nsplit = typesize if (split and typesize <= 16 and blocksize // typesize >= 128 and not leftover) else 1
+        ne = len(blk) // nsplit
+        body = bytearray()
+        for k in range(nsplit):
+            part = blk[k * ne:(k + 1) * ne]
+            comp = _lz4_encode(part) if codec == "lz4" else _z.compress(part, 1)
+            if len(comp) >= len(part):
+                comp = part                                   # stored stream: compressed size == uncompressed size
+            body += len(comp).to_bytes(4, "little") + comp
+        blocks.append(bytes(body))
+    starts, pos = [], 16 + 4 * nblocks
+    for blk in blocks:
+        starts.append(pos); pos += len(blk)
+    head = bytes([2, 1, flags, typesize]) + nbytes.to_bytes(4, "little") + blocksize.to_bytes(4, "little") + pos.to_bytes(4, "little")
+    return head + b"".join(x.to_bytes(4, "little") for x in starts) + b"".join(blocks)
+
+
+@pytest.mark.parametrize("dtype,shuffle,codec,split", [("<u2", "byte", "lz4", True), ("<f4", "byte", "lz4", False), ("u1", "none", "lz4", True),
+                                                       ("<u8", "bit", "lz4", True), ("<f4", "byte", "zlib", True)])
+def test_blosc_frames_laid_down_by_hand(tmp_path, dtype, shuffle, codec, split):
+    """zarr's default compressor: Blosc frames (lz4 / zlib inside, byte / bit shuffle, split and unsplit blocks, a short last block,
+    a stored stream) built by hand from the frame layout with the test's own LZ4 encoder, read back through blosc_decode, through
+    both LZ4 decoders, and through an array whose .zarray names the blosc compressor.  (Unpinned against numcodecs: not installed.)"""
+    rng = np.random.default_rng(5)
+    ref = (np.cumsum(rng.integers(0, 3, size=(6, 40, 50)), axis=2) * (rng.random((6, 40, 50)) > 0.2)).astype(dtype)   # compressible, with runs
+    ref[1] = rng.integers(0, 2 ** 8, size=(40, 50)).astype(dtype)                                                       # one noisy plane
+    payload = ref.tobytes()
+    ts = np.dtype(dtype).itemsize
+    frame = _blosc_frame(payload, ts, 4096 * ts, shuffle, codec, split)
+    assert len(frame) < len(payload)
+    assert zarrio.blosc_decode(frame) == payload
+    sample = payload[:5000]
+    enc = _lz4_encode(sample)
+    assert zarrio._lz4_block_py(enc, len(sample)) == sample and zarrio._lz4_block(enc, len(sample)) == sample
+    assert zarrio._lz4_block_py(_lz4_encode(b"ab" * 300 + b"tail!"), 605) == b"ab" * 300 + b"tail!"      # overlapping match (offset 2)
+    root = str(tmp_path / "bl.zarr")
+    os.makedirs(root)
+    json.dump({"zarr_format": 2, "shape": [6, 40, 50], "chunks": [6, 40, 50], "dtype": np.dtype(dtype).str, "order": "C", "fill_value": 0,
+               "filters": None, "compressor": {"id": "blosc", "cname": codec, "clevel": 5, "shuffle": 1, "blocksize": 0}},
+              open(os.path.join(root, ".zarray"), "w"))
+    open(os.path.join(root, "0.0.0"), "wb").write(frame)
+    a = zarrio.open(root)
+    assert np.array_equal(a[...], ref)
+    with pytest.raises(NotImplementedError):
+        zarrio.open(root, mode="r+")[0, 0, 0] = 1               # Blosc chunks are read-only here
+    stored = bytes([2, 1, 0x2, ts]) + len(payload).to_bytes(4, "little") * 2 + (16 + len(payload)).to_bytes(4, "little") + payload
+    assert zarrio.blosc_decode(stored) == payload               # memcpy frame
+    bad = bytearray(frame); bad[2] = (bad[2] & 0x1f) | (4 << 5)
+    with pytest.raises(NotImplementedError, match="zstd"):
+        zarrio.blosc_decode(bytes(bad))
 
 
 def test_prepare_and_open_ds(tmp_path):
@@ -96,3 +202,35 @@ def test_prepare_and_open_ds(tmp_path):
     a[:, 5:10, 0:6, 7:14] = 1.5
     b = zarrio.open_ds(str(tmp_path / "p.zarr"), "volumes/pred")
     assert b.voxel_size == (4, 4, 4) and b.offset == (40, 0, 8) and b[1, 7, 3, 9] == 1.5 and b[1, 0, 0, 0] == 0
+
+
+def test_n5_dataset_laid_down_by_hand(tmp_path):
+    """An N5 dataset written by hand from the N5 spec (attributes.json in fastest-axis-first order, big-endian blocks with the
+    [mode, ndim, dims] header, gzip and raw compression, cropped edge blocks, a missing block) read through open_ds."""
+    import gzip as _gz
+    ref = (np.arange(5 * 6 * 7).reshape(5, 6, 7) * 3).astype(np.uint16)       # numpy order (z, y, x)
+    for comp in ("gzip", "raw"):
+        root = tmp_path / f"{comp}.n5"
+        ds = root / "volumes" / "raw"
+        os.makedirs(ds)
+        json.dump({"dimensions": [7, 6, 5], "blockSize": [4, 3, 2], "dataType": "uint16", "compression": {"type": comp},
+                   "resolution": [4, 8, 40], "offset": [0, 16, 80]}, open(ds / "attributes.json", "w"))
+        for bz in range(3):
+            for by in range(2):
+                for bx in range(2):
+                    if (bz, by, bx) == (2, 1, 1):
+                        continue                                   # missing block = zeros
+                    blk = ref[bz * 2:bz * 2 + 2, by * 3:by * 3 + 3, bx * 4:bx * 4 + 4]
+                    dims = list(reversed(blk.shape))               # N5 order: x, y, z
+                    payload = blk.astype(">u2").tobytes()
+                    head = (0).to_bytes(2, "big") + (3).to_bytes(2, "big") + b"".join(d.to_bytes(4, "big") for d in dims)
+                    os.makedirs(ds / str(bx) / str(by), exist_ok=True)
+                    open(ds / str(bx) / str(by) / str(bz), "wb").write(head + (_gz.compress(payload) if comp == "gzip" else payload))
+        a = zarrio.open_ds(str(root), "volumes/raw")
+        want = ref.copy(); want[4:, 3:, 4:] = 0
+        assert a.shape == (5, 6, 7) and a.chunks == (2, 3, 4) and a.voxel_size == (40, 8, 4) and a.offset == (80, 16, 0)
+        got = a[...]
+        assert got.dtype == np.uint16 and np.array_equal(got, want)
+        assert np.array_equal(a[1:4, 2:5, 3:7], want[1:4, 2:5, 3:7])
+        with pytest.raises(NotImplementedError):
+            a[0, 0, 0] = 1
