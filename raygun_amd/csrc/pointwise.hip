@@ -948,6 +948,57 @@ __global__ void subpixel_w_bwd_kernel(const float* gwf, const float* gweff, Subp
     dw[o * q.so + (long)c * q.sc + td * q.sd + th * q.sh + tw * q.sw] = v;
   }
 }
+// float4 forms for channels-last weights (input-channel stride 1, split and channel counts multiples of 4): four consecutive input
+// channels per thread, 32-bit index arithmetic — the scalar kernels above spend their time in 64-bit divisions (0.33 / 0.17 ms for
+// config U's 3024 -> 432 layer, 450 MB each way).
+__device__ __forceinline__ float4 f4add(float4 a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; return a; }
+__global__ __launch_bounds__(256) void subpixel_w_fwd4_kernel(const float* w, SubpixW q, float* wf, float* weff) {
+  const unsigned cg4 = (unsigned)(q.C - q.cf) / 4, cf4 = (unsigned)q.cf / 4;
+  const unsigned n_eff = 64u * (unsigned)q.O * cg4, n_f = (unsigned)q.O * 27u * cf4;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n_eff + n_f; e += gridDim.x * blockDim.x) {
+    if (e < n_eff) {
+      const unsigned i4 = e % cg4; unsigned r = e / cg4;
+      const unsigned s = r & 7; r >>= 3;
+      const unsigned o = r % (unsigned)q.O, p = r / (unsigned)q.O;
+      int d0, nd, h0, nh, w0, nw;
+      subpix_taps((p >> 2) & 1, (s >> 2) & 1, d0, nd); subpix_taps((p >> 1) & 1, (s >> 1) & 1, h0, nh); subpix_taps(p & 1, s & 1, w0, nw);
+      const float* base = w + (long)o * q.so + q.cf + 4 * i4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c)
+        acc = f4add(acc, *(const float4*)(base + (d0 + a) * q.sd + (h0 + b) * q.sh + (w0 + c) * q.sw));
+      ((float4*)weff)[e] = acc;
+    } else {
+      const unsigned f = e - n_eff;
+      const unsigned i4 = f % cf4; unsigned r = f / cf4;
+      const unsigned t = r % 27u, o = r / 27u;
+      ((float4*)wf)[f] = *(const float4*)(w + (long)o * q.so + 4 * i4 + (t / 9) * q.sd + ((t / 3) % 3) * q.sh + (t % 3) * q.sw);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void subpixel_w_bwd4_kernel(const float* gwf, const float* gweff, SubpixW q, float* dw) {
+  const unsigned C4 = (unsigned)q.C / 4, cf4 = (unsigned)q.cf / 4, cg4 = C4 - cf4;
+  const unsigned n = (unsigned)q.O * 27u * C4;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const unsigned c4 = e % C4; unsigned r = e / C4;
+    const unsigned t = r % 27u, o = r / 27u;
+    const int td = t / 9, th = (t / 3) % 3, tw = t % 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < cf4) { if (gwf) v = ((const float4*)gwf)[(o * 27u + t) * cf4 + c4]; }
+    else if (gweff) {
+      const unsigned i4 = c4 - cf4;
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int k = 0; k < 2; ++k) {
+        const int pd = a, sd = td == 0 ? 0 : td == 2 ? 1 : a, ph = b, sh = th == 0 ? 0 : th == 2 ? 1 : b, pw = k, sw = tw == 0 ? 0 : tw == 2 ? 1 : k;
+        const unsigned p = (pd << 2) | (ph << 1) | pw, sx = (sd << 2) | (sh << 1) | sw;
+        v = f4add(v, ((const float4*)gweff)[((p * (unsigned)q.O + o) * 8u + sx) * cg4 + i4]);
+      }
+    }
+    *(float4*)(dw + (long)o * q.so + 4 * c4 + td * q.sd + th * q.sh + tw * q.sw) = v;
+  }
+}
+static bool subpix_vec4(const SubpixW& q, const void* a, const void* b, const void* c) {
+  return q.sc == 1 && q.cf % 4 == 0 && q.C % 4 == 0 && q.so % 4 == 0 && q.sd % 4 == 0 && q.sh % 4 == 0 && q.sw % 4 == 0 &&
+         (((size_t)a | (size_t)b | (size_t)c) & 15) == 0 && (double)q.O * 64.0 * q.C < 4.0e9;
+}
 static int subpix_desc(const rg_tensor* w, int cf, SubpixW* q, const char* what) {
   if (!w || !w->ptr || w->dtype != RG_F32 || w->rank != 5 || w->sizes[2] != 3 || w->sizes[3] != 3 || w->sizes[4] != 3)
     { rg_set_error("%s: expected an fp32 (O, C, 3, 3, 3) weight", what); return RG_ERR_BAD_SHAPE; }
@@ -962,6 +1013,10 @@ extern "C" int rg_subpixel_weights(const rg_tensor* w, int cf, float* wf, float*
   if (!weff || (cf > 0 && !wf)) RG_FAIL(RG_ERR_BAD_SHAPE, "subpixel_weights: null output");
   const long n = (long)64 * q.O * (q.C - q.cf) + (long)q.O * 27 * q.cf;
   long blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  if (subpix_vec4(q, w->ptr, wf, weff)) {
+    blocks = (n / 4 + 255) / 256; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(subpixel_w_fwd4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const float*)w->ptr, q, wf, weff);
+  } else
   hipLaunchKernelGGL(subpixel_w_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const float*)w->ptr, q, wf, weff);
   RG_CHECK_LAUNCH();
   return RG_OK;
@@ -971,6 +1026,10 @@ extern "C" int rg_subpixel_weights_bwd(const float* g_wf, const float* g_weff, c
   if ((rc = subpix_desc(dw, cf, &q, "subpixel_weights_bwd"))) return rc;
   const long n = (long)q.O * 27 * q.C;
   long blocks = (n + 255) / 256; if (blocks > 65536) blocks = 65536;
+  if (subpix_vec4(q, dw->ptr, g_wf, g_weff)) {
+    blocks = (n / 4 + 255) / 256; if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(subpixel_w_bwd4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, g_wf, g_weff, q, (float*)dw->ptr);
+  } else
   hipLaunchKernelGGL(subpixel_w_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, g_wf, g_weff, q, (float*)dw->ptr);
   RG_CHECK_LAUNCH();
   return RG_OK;
