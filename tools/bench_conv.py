@@ -10,10 +10,15 @@ shapes=[ # cin,cout,in_spatial,k
 sel=[int(v) for v in sys.argv[1].split(',')] if len(sys.argv)>1 else None
 if sel is not None: shapes=[shapes[i] for i in sel]
 for cin,cout,s,k in shapes:
+    zero=bool(os.environ.get('RG_ZERO_DATA'))
     x=torch.randn(1,cin,s,s,s,device=dev).to(torch.bfloat16); x=ops.to_cl(x)
+    if zero: x.zero_()
     w=(torch.randn(cout,cin,k,k,k,device=dev)*0.05).requires_grad_(True); b=torch.zeros(cout,device=dev)
     xg=x.detach().requires_grad_(cin>1)
+    if zero:
+        with torch.no_grad(): w.zero_()
     y=ops.conv3d(xg,w,b,1,0,'relu'); g=torch.randn_like(y)
+    if zero: g.zero_()
     for rep in range(2):
         ops.profile_start()
         y=ops.conv3d(xg,w,b,1,0,'relu')
