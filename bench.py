@@ -365,17 +365,27 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
+    # Every conv launch of the LAST warm-up step is bracketed by HIP events (the per-kernel table below); inside the timed region only
+    # the dominant kernel of that table is (its roofline numbers are measured live there): an event pair costs ~50 us of host time and
+    # stops neighbouring kernels from overlapping — fully instrumented the step measures ~4 % slower.
+    table, select = None, None
+    for i in range(warmup):
+        if i == warmup - 1:
+            ops.profile_start()
         step(sync)
+    if warmup:
+        table = ops.profile_stop()
+        if table:
+            select = ops.profile_signatures().get(max(table.items(), key=lambda kv: kv[1]["ms"])[0])
     barrier()
-    ops.profile_start()
+    ops.profile_start(select)
     t0 = time.perf_counter()
     for _ in range(steps):
         step(sync)
+    t_enq = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind); close to dt = launch-bound
     barrier()
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
-    sync.detach()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -383,18 +393,22 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
     if rank != 0:
         return None
     ms = dt / steps * 1e3
-    kernels = {k: dict(launches=v["launches"] // steps, ms_per_step=v["ms"] / steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0)
-               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    tab, tsteps = (table, 1) if table else (prof, steps)  # per-kernel table: the instrumented warm-up step (all conv launches)
+    kernels = {k: dict(launches=v["launches"] // tsteps, ms_per_step=v["ms"] / tsteps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0.0)
+               for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])}
+    dom, dsteps = (max(tab.items(), key=lambda kv: kv[1]["ms"]) if tab else None), tsteps
+    if dom and dom[0] in prof:
+        dom, dsteps = (dom[0], prof[dom[0]]), steps   # the dominant kernel's launches of the TIMED steps
     roofline = None
     if dom:
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(dom[0]) if workload == "unet" else None,
                         traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_pmc_*.csv passes of this workload",
-                        launches_per_step=dom[1]["launches"] // steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
+                        launches_per_step=dom[1]["launches"] // dsteps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4),
+                        measured="HIP events around this kernel's launches inside the timed region; the `kernels` table is the fully instrumented last warm-up step")
     flop = (UNET_FLOP_PER_STEP if workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if workload == "unet" else 128)) ** 3
-    executed = sum(v["flops"] for v in prof.values()) / steps  # what the conv / weight-gradient launches actually multiplied
+    executed = sum(v["flops"] for v in tab.values()) / tsteps  # what the conv / weight-gradient launches actually multiplied
     res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if workload == "unet" else "CycleGAN 128^3 train-step ms",
                value=round(size ** 3 * world / (dt / steps) / 1e6, 3) if workload == "unet" else round(ms, 3),
                unit="Mvoxels/s" if workload == "unet" else "ms/step", n_gpus=world, steps=steps, warmup=warmup,
@@ -407,6 +421,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
                algorithmic_tflop_per_step=round(flop / 1e12, 3), executed_tflop_per_step=round(executed / 1e12, 3),
                step_tflops=round(flop / (dt / steps) / 1e12, 2), executed_tflops=round(executed / (dt / steps) / 1e12, 2),
                step_frac_of_mfma_peak=round(flop / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+               host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 3),
                executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                roofline=roofline, kernels=kernels)
     return res

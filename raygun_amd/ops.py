@@ -315,10 +315,24 @@ def _conv_params(R, T, rstride, tbase, tstep, ostride, ooffset, cout, act="none"
 _prof = None
 
 
-def profile_start():
-    """Start recording a HIP-event pair (on torch's current stream = the launch stream) around every conv kernel."""
-    global _prof
+_prof_select = None   # None: every conv launch is timed; else only the problems whose signature is in this set
+_prof_sigs = {}       # kernel name -> problem signatures, from the last session that timed everything
+
+
+def profile_signatures():
+    """kernel name -> set of problem signatures seen by the last profile session that timed every launch."""
+    return _prof_sigs
+
+
+def profile_start(select=None):
+    """Start recording a HIP-event pair (on torch's current stream = the launch stream) around every conv kernel, or — `select`
+    = an iterable of problem signatures from profile_signatures() — only around those problems: an event pair costs ~50 us of
+    host time and keeps neighbouring kernels from overlapping (the U-Net step measures 4 % slower fully instrumented), so
+    bench.py instruments everything in the warm-up steps and only the dominant kernel inside the timed region.  Weight-gradient
+    calls are bracketed inside the library (main kernel only) in both modes."""
+    global _prof, _prof_select
     _prof = []
+    _prof_select = None if select is None else set(select)
     L = _lib.lib("bf16")
     L.rg_profile_enable(1)  # weight-gradient calls: event pair around the main kernel only, inside the library
     L.rg_profile_drain(None, 0)
@@ -326,7 +340,7 @@ def profile_start():
 
 def profile_stop():
     """-> {kernel name: dict(launches, ms, flops)} ; algorithmic flops = 2*rows*taps*Cin*Cout per launch."""
-    global _prof
+    global _prof, _event_next, _prof_sigs
     rec, _prof = _prof, None
     torch.cuda.synchronize()
     L = _lib.lib("bf16")
@@ -335,30 +349,56 @@ def profile_stop():
     buf = (C.c_float * max(1, len(marked)))()
     got = L.rg_profile_drain(buf, len(marked))
     inner = dict(zip(map(id, marked), buf[:got])) if got == len(marked) else {}
-    out = {}
+    out, sigs = {}, {}
     for r in rec or []:
-        name, flops, e0, e1, _ = r
+        name, flops, e0, e1, _, sig = r
+        ms = inner.get(id(r), None) or (e0.elapsed_time(e1) if e0 is not None else None)
+        if ms is None:
+            continue
         d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
         d["launches"] += 1
-        d["ms"] += inner.get(id(r), None) or e0.elapsed_time(e1)
+        d["ms"] += ms
         d["flops"] += flops
+        if sig is not None:
+            sigs.setdefault(name, set()).add(sig)
+    if _prof_select is None:
+        _prof_sigs = sigs
+    _event_next = 0
     return out
 
 
 profile_shapes = False  # True: key the records by kernel name AND problem shape (diagnostics)
 
 
+_event_pool, _event_next = [], 0  # timing events are reused across profile sessions: creating two per launch cost more host time than the launch
+
+
+def _event():
+    global _event_next
+    if _event_next == len(_event_pool):
+        _event_pool.append(torch.cuda.Event(enable_timing=True))
+    _event_next += 1
+    return _event_pool[_event_next - 1]
+
+
 def _timed(flops, fn, tag=None, marked=False, name=None):
     if _prof is None:
         return fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    sig = tag() if tag is not None else None
+    timed = _prof_select is None or sig in _prof_select
+    if not timed and not marked:
+        return fn()
+    e0 = e1 = None
+    if timed and not (marked and _prof_select is not None):   # selected weight gradients: the library's own event pair is enough
+        e0, e1 = _event(), _event()
+        e0.record()
     r = fn()
-    e1.record()
+    if e1 is not None:
+        e1.record()
     name = name() if name is not None else _L().rg_last_kernel_name().decode()
-    if profile_shapes and tag is not None:
-        name += " " + tag()
-    _prof.append((name, flops, e0, e1, marked))
+    if profile_shapes and sig is not None:
+        name += " " + sig
+    _prof.append((name, flops, e0, e1, marked, sig))
     return r
 
 
