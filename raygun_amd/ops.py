@@ -421,13 +421,17 @@ def _igemm(x, wp, bias, y, p):
 WINO_MIN_CHANNELS = 1024  # Winograd F(2,3)^3 only where K = Cin is long (config U's 2592 -> 2592 level); see csrc/winograd.hip
 
 
-def _wino_ok(weight, stride, padding, dw_swapped):
-    """Winograd path for this convolution?  Both storage types: the transform-domain rounding doubles THAT layer's error, but at
-    network level config U's f16 outputs stay where they were (7.6e-4 / 8.5e-4 / 8.4e-4 relative L2 against 8.6e-4 / 7.5e-4 / 8.8e-4
-    direct, tools/f16_wino_probe.py; asserted <= 1e-3 in tests/test_networks_gpu.py)."""
+def _wino_ok(weight, stride, padding, dw_swapped, backward=False):
+    """Winograd path for this convolution's forward (backward=False) or backward-data pass?  Each pass is judged by ITS reduction
+    length — input channels forward, output channels backward — which must be >= WINO_MIN_CHANNELS (the transform-domain tensors are
+    8x the activations: short reductions do not pay), the other side >= 128 (the GEMM's column tiles).  Config U: both passes of
+    2592 -> 2592, and the backward-data pass of 432 -> 2592.  Both storage types: the transform-domain rounding doubles THAT layer's
+    error, but at network level config U's f16 outputs stay where they were (7.6e-4 / 8.5e-4 / 8.4e-4 relative L2 against 8.6e-4 /
+    7.5e-4 / 8.8e-4 direct, tools/f16_wino_probe.py; asserted <= 1e-3 in tests/test_networks_gpu.py)."""
+    red, cols = (weight.shape[0], weight.shape[1]) if backward else (weight.shape[1], weight.shape[0])
     return (os.environ.get("RAYGUN_AMD_WINOGRAD", "1") != "0" and not dw_swapped
             and tuple(weight.shape[2:]) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (0, 0, 0)
-            and weight.shape[0] >= WINO_MIN_CHANNELS and weight.shape[1] >= WINO_MIN_CHANNELS and weight.dtype == torch.float32
+            and red >= WINO_MIN_CHANNELS and cols >= min(128, WINO_MIN_CHANNELS) and weight.dtype == torch.float32
             and (is_cl_weight(weight) or weight.is_contiguous()))
 
 
@@ -656,8 +660,8 @@ class _Conv3d(Function):
                                f"Kernel size: {K}. Kernel size can't be greater than actual input size")
         y = alloc(n, cout, *O, x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        ctx.wino = _wino_ok(weight, stride, padding, dw_swapped)
-        if ctx.wino:
+        ctx.wino = _wino_ok(weight, stride, padding, dw_swapped, backward=True)
+        if _wino_ok(weight, stride, padding, dw_swapped):
             _wino_conv(x, _wino_weights(weight)[0], b, act, slope, y, 0)
         else:
             wp = pack_weights(weight, swap=0)
