@@ -1,0 +1,21 @@
+"""Host-side decisions that need no GPU (run in the CPU suite)."""
+import os
+def test_winograd_gating_is_per_pass():
+    """ops._wino_ok (host logic, no GPU): a pass takes the Winograd path when ITS reduction length reaches WINO_MIN_CHANNELS — config U's
+    2592 -> 2592 level both ways, 432 -> 2592 only in the backward-data pass — and never for strides, paddings, other kernel sizes, the
+    D<->W exchanged form or when switched off."""
+    import torch
+    from raygun_amd import ops
+    w_sq = torch.empty(2592, 2592, 3, 3, 3, device="meta")
+    w_up = torch.empty(2592, 432, 3, 3, 3, device="meta")
+    ok = lambda w, **kw: ops._wino_ok(w, kw.get("stride", (1, 1, 1)), kw.get("padding", (0, 0, 0)), kw.get("dw", False), backward=kw.get("backward", False))  # noqa: E731
+    assert ok(w_sq) and ok(w_sq, backward=True)
+    assert not ok(w_up) and ok(w_up, backward=True)
+    assert not ok(torch.empty(432, 2592, 3, 3, 3, device="meta"), backward=True) and ok(torch.empty(432, 2592, 3, 3, 3, device="meta"))
+    assert not ok(w_sq, stride=(2, 2, 2)) and not ok(w_sq, padding=(1, 1, 1)) and not ok(w_sq, dw=True)
+    assert not ok(torch.empty(2592, 2592, 2, 2, 2, device="meta")) and not ok(torch.empty(2592, 64, 3, 3, 3, device="meta"), backward=True)
+    os.environ["RAYGUN_AMD_WINOGRAD"] = "0"
+    try:
+        assert not ok(w_sq)
+    finally:
+        del os.environ["RAYGUN_AMD_WINOGRAD"]

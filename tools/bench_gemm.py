@@ -18,8 +18,5 @@ def run(B, m, k, n, reps=5):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / reps
     print(f"B={B:3d} m={m:5d} k={k:6d} n={n:5d}: {t:.3f} ms  {2.0*B*m*k*n/t/1e9:7.0f} TF/s  {L.rg_last_kernel_name().decode()}", flush=True)
-for cfg in [(64, 729, 2592, 2592), (64, 1000, 2592, 2592), (1, 729 * 64, 2592, 2592)]:
+for cfg in [(64, 729, 2592, 2592), (64, 1000, 2592, 2592), (64, 2592, 768, 2592), (64, 2592, 729, 2592), (64, 2592, 1024, 2592)]:
     run(*cfg)
-print("K sweep of rg_gemm_batched:")
-for k in (2432, 2496, 2560, 2592, 2624, 2688, 2752):
-    run(64, 729, k, 2592)
