@@ -6,7 +6,8 @@ valid, 259 146 829 parameters, num_affs 3) affinity train step on a synthetic 19
 forward + WeightedMSELoss_MTLSD + backward + Adam (+ RCCL gradient all-reduce for N > 1), bf16 storage /
 fp32 accumulate.  value = input Mvoxels/s over the whole job (196^3 * N / step time), "scaling": "weak".
 The same run then times the 3-D CycleGAN link train step at 128^3 (BASELINE's second figure, ms/step) and reports it under
-`secondary` in the same line (`--no-secondary` skips it; `--workload cyclegan` times only that).  With --gpus N > 1 and no
+`secondary` in the same line at N = 1 (`--no-secondary` skips it, `--secondary-dp` adds it to N > 1 runs; `--workload cyclegan` times
+only that).  With --gpus N > 1 and no
 launcher (no RANK in the environment) bench.py starts its own N rank processes (RCCL).
 `--workload predict` times block-wise volume prediction (first half: 196^3 -> 104^3 blocks of the
 U-Net with 20 affinity channels over a synthetic uint8 volume resident in HBM); `--workload segment` times the mutex
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="unet workload: do not also time the CycleGAN 128^3 step")
+    ap.add_argument("--secondary-dp", action="store_true", help="with --gpus N > 1: time the CycleGAN step data-parallel as well (default: N = 1 only, "
+                    "so that the scaling runs carry one workload and one set of collectives)")
     ap.add_argument("--cpu-size", type=int, default=0)
     return ap.parse_args()
 
@@ -446,7 +449,7 @@ def main():
         return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
     res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev)
-    if a.workload == "unet" and not a.no_secondary:
+    if a.workload == "unet" and not a.no_secondary and (world == 1 or a.secondary_dp):
         # BASELINE's metric string has a second half — "CycleGAN 128^3 train-step ms" (config 2; with N > 1: config 4): timed in
         # the same run, after the U-Net's memory is released, and reported inside the same JSON line
         import gc
