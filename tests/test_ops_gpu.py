@@ -643,3 +643,27 @@ def test_thin_weight_gradient_blocks_of_lines(cin, cout, sp):
     prof = ops.profile_stop()
     assert any(n.startswith("wgrad_lines_kernel") for n in prof), list(prof)
     assert relerr(gw, gwr) <= TOL, relerr(gw, gwr)
+
+
+@pytest.mark.gpu
+def test_winograd_operands_follow_the_optimizer(monkeypatch):
+    """The transformed weights (U, Ut) are cached on the parameter like the packed operands: after a FusedAdam step (and after a plain
+    in-place update through torch.optim) the next forward must see the NEW weights — compared with the direct kernels on the same
+    parameter."""
+    from raygun_amd import ops
+    from raygun_amd.torch.optimizers import FusedAdam
+    monkeypatch.setattr(ops, "WINO_MIN_CHANNELS", 64)
+    dev = torch.device("cuda")
+    x = rnd((1, 96, 8, 9, 10), 95).to(dev)
+    for make_opt in (lambda p: FusedAdam([p], lr=5e-2), lambda p: torch.optim.SGD([p], lr=5.0)):
+        w = torch.nn.Parameter(rnd((144, 96, 3, 3, 3), 96, -0.05, 0.05).to(dev).contiguous(memory_format=torch.channels_last_3d))
+        opt = make_opt(w)
+        y0 = ops.conv3d(x, w, None, 1, 0, "none", 0.0)
+        y0.float().pow(2).mean().backward()
+        opt.step()
+        y1 = ops.conv3d(x, w, None, 1, 0, "none", 0.0)
+        monkeypatch.setenv("RAYGUN_AMD_WINOGRAD", "0")
+        y1d = ops.conv3d(x, w, None, 1, 0, "none", 0.0)
+        monkeypatch.delenv("RAYGUN_AMD_WINOGRAD")
+        assert relerr(y1, y0) > 5e-2, "the step did not change the output: stale transformed weights"
+        assert relerr(y1, y1d) <= TOL, relerr(y1, y1d)
