@@ -55,6 +55,7 @@ def build_unet(dev, size, seed):
     from raygun_amd.torch.models import MTLSDModel
     from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
     from raygun_amd.torch.optimizers import FusedAdam
+    from raygun_amd import parallel
     torch.manual_seed(1234)  # identical random-init weights on every rank
     with torch.device(dev):
         model = MTLSDModel(num_affs=3)
@@ -74,7 +75,11 @@ def build_unet(dev, size, seed):
         opt.zero_grad(set_to_none=True)
         affs, lsds = model(raw)
         loss = loss_fn(lsds, gt_l, w_l, affs, gt_a, w_a)
-        loss.backward()
+        ws = parallel.world_size()
+        if ws > 1 and sync.prescaled:   # mean over ranks = sum of gradients of loss / world: no division pass over 1 GB of gradients
+            loss.backward(torch.full_like(loss, 1.0 / ws))
+        else:
+            loss.backward()
         sync([p for p in model.parameters()])
         opt.step()
         return loss
@@ -361,7 +366,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
     from raygun_amd import ops, parallel
     with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
         step, info = (build_unet if workload == "unet" else build_cyclegan)(dev, size, seed=rank)
-    sync = parallel.GradSync()
+    sync = parallel.GradSync(prescaled=(workload == "unet"))
 
     def barrier():
         if world > 1:

@@ -47,6 +47,14 @@ def _worker(rank, world, port, out, overlap=False):
     ref.load_state_dict(net.state_dict())
     ref(data).pow(2).mean().backward()
     err = max(float((p.grad - q.grad).abs().max()) for p, q in zip(net.parameters(), ref.parameters()))
+    # prescaled mode (bench.py's U-Net step): the backward is seeded with 1 / world, the SUM is then the mean and nothing is divided
+    pre = parallel.GradSync(prescaled=True, small_bytes=64, bucket_bytes=256)
+    for q in net.parameters():
+        q.grad = None
+    loss = net(data[rank:rank + 1]).pow(2).mean()
+    loss.backward(torch.full_like(loss, 1.0 / world))
+    pre(list(net.parameters()))
+    err = max(err, max(float((p.grad - q.grad).abs().max()) for p, q in zip(net.parameters(), ref.parameters())))
     blocks = list(parallel.shard_blocks(7))
     out.put((rank, err, blocks, [float(p.detach().sum()) for p in net.parameters()]))
     torch.distributed.destroy_process_group()
