@@ -235,7 +235,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
   const unsigned T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
   const unsigned N = (unsigned)((long)Z * Y * X);
   const unsigned ne = *count;
-  unsigned bar_target = 0, next = 0, nsurv = 0;
+  unsigned bar_target = 0, next = 0, nsurv = 0, pend = 0;   // pend: list operations of the previous round, applied at the head of this one
   uint4* win = win0; uint4* wout = win1;
   for (unsigned round = 1;; ++round) {
     // fresh edges this round: top the window up to ~2 entries per thread (the survivors already hold the earliest pending
@@ -247,6 +247,26 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
     if (n == 0) break;
     const u64 tag = (u64)round << 32;
     const u64 c0 = wall_clock64();
+    // ---- phase C of the PREVIOUS round, in the same barrier interval as phase A: mutex-list surgery by atomic appends to the CURRENT
+    // roots.  Phase A does not walk lists (it reads cnt only to decide whether the pair cache is worth a look, and a cache hit is a
+    // fact whatever cnt says), parents are not changed by either part (path halving aside), and phase B — the list walker — starts
+    // behind the barrier: the third grid barrier of a round and its own chain of dependent loads are gone.
+    if (pend) {
+      const int2* po = ops + (size_t)((round - 1) & 1) * cap;
+      for (unsigned i = tid; i < pend; i += T) {
+        const int2 op = po[i];
+        if (op.y < 0) mws_list_append(s, mws_find(s.parent, op.x), s.head[op.x], s.tail[op.x], s.cnt[op.x]);
+        else {
+          const unsigned na = atomicAdd(&ctl->pool_used, 2u), nb = na + 1;
+          if (nb < pool_cap) {
+            // only .x is written: .y is -1 from the initial fill, and once the node is published by the exchange below another
+            // thread may already be linking its own chain behind it
+            s.pool[na].x = op.y; mws_list_append(s, mws_find(s.parent, op.x), (int)na, (int)na, 1);
+            s.pool[nb].x = op.x; mws_list_append(s, mws_find(s.parent, op.y), (int)nb, (int)nb, 1);
+          }
+        }
+      }
+    }
     // ---- phase A
     for (unsigned i = tid; i < n; i += T) {
       uint4 e;
@@ -280,6 +300,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
     // ---- phase B
     unsigned* surv = &ctl->surv[round & 1];
     unsigned* nops = &ctl->nops[round & 1];
+    int2* const ops_w = ops + (size_t)(round & 1) * cap;
     for (unsigned i0 = tid - lane; i0 < n; i0 += T) {  // whole waves iterate together (ballots below)
       const unsigned i = i0 + lane;
       uint4 e = make_uint4(MWS_RETIRED, 0, 0, 0);
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(nops, (unsigned)__popcll(om));
         base = __shfl(base, 0);
-        if (op.x >= 0) ops[base + __popcll(om & ((1ull << lane) - 1ull))] = op;
+        if (op.x >= 0) ops_w[base + __popcll(om & ((1ull << lane) - 1ull))] = op;
       }
     }
     mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
@@ -327,24 +348,8 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
     const unsigned no = __hip_atomic_load(nops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     next += want;
     if (tid == 0) { ctl->surv[(round + 1) & 1] = 0; ctl->nops[(round + 1) & 1] = 0; ctl->rounds = round; }  // everyone read those before the last barrier
-    // ---- phase C
-    if (no) {
-      for (unsigned i = tid; i < no; i += T) {
-        const int2 op = ops[i];
-        if (op.y < 0) mws_list_append(s, mws_find(s.parent, op.x), s.head[op.x], s.tail[op.x], s.cnt[op.x]);
-        else {
-          const unsigned na = atomicAdd(&ctl->pool_used, 2u), nb = na + 1;
-          if (nb < pool_cap) {
-            // only .x is written: .y is -1 from the initial fill, and once the node is published by the exchange below another
-            // thread may already be linking its own chain behind it
-            s.pool[na].x = op.y; mws_list_append(s, mws_find(s.parent, op.x), (int)na, (int)na, 1);
-            s.pool[nb].x = op.x; mws_list_append(s, mws_find(s.parent, op.y), (int)nb, (int)nb, 1);
-          }
-        }
-      }
-      mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
-    }
-    if (tid == 0) { ctl->t[0] += c1 - c0; ctl->t[1] += c2 - c1; ctl->t[2] += wall_clock64() - c2; ctl->visits += n; }
+    pend = no;   // applied at the head of the next round (the last round's operations are never needed: labels come from the parents)
+    if (tid == 0) { ctl->t[0] += c1 - c0; ctl->t[1] += c2 - c1; ctl->visits += n; }
     if (ns2 == n || round > (1u << 23)) {  // no edge retired although the earliest one always can: never expected; leave instead of spinning
       if (tid == 0) ctl->stalled = 1;
       break;
@@ -407,7 +412,7 @@ static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
   o += al((size_t)q->pool_nodes * 8); q->off_claim = o;
   o += al((size_t)q->N * 8); q->off_pairs = o;
   o += al((size_t)8 << MWS_PAIR_BITS); q->off_ops = o;
-  o += al((size_t)MWS_WIN_CAP * 8); q->off_win = o;
+  o += 2 * al((size_t)MWS_WIN_CAP * 8); q->off_win = o;   // two operation buffers (round parity)
   o += 2 * al((size_t)MWS_WIN_CAP * 16); q->off_first = o;
   o += al((size_t)q->N * 4); q->off_flags = o;
   o += al((size_t)q->N * 4); q->off_rank = o;
@@ -541,7 +546,7 @@ static int mws_graph_plan(int64_t n_nodes, int64_t n_edges, MwsGraphPlan* q) {
   q->off_pool = o; o += al((size_t)q->pool_nodes * 8);
   q->off_claim = o; o += al((size_t)q->N * 8);
   q->off_pairs = o; o += al((size_t)8 << MWS_PAIR_BITS);
-  q->off_ops = o; o += al((size_t)MWS_WIN_CAP * 8);
+  q->off_ops = o; o += 2 * al((size_t)MWS_WIN_CAP * 8);
   q->off_win = o; o += 2 * al((size_t)MWS_WIN_CAP * 16);
   q->off_first = o; o += al((size_t)q->N * 4);
   q->off_flags = o; o += al((size_t)q->N * 4);
