@@ -39,7 +39,6 @@ struct Igemm2Args {
   int act; float slope;
   long M;
   int tiles_m, tiles_n;
-  int exp;  // experiment bits (RG_EXP env): 1 = no DMA in the loop, 2 = no MFMA
   int check_bounds;  // 0 when every tap of every row lies inside the input volume (valid convolutions)
 };
 
@@ -290,7 +289,6 @@ int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const flo
   a.cout = p->cout; a.cout_lanes = Y.lanes; a.wrows = round_up(p->cout, 16);
   a.act = p->act; a.slope = p->slope;
   a.M = (long)X.N * a.RD * a.RH * a.RW;
-  { const char* e = getenv("RG_EXP"); a.exp = e ? atoi(e) : 0; }
   a.check_bounds = 0;
   {
     const int I[3] = {X.D, X.H, X.W};
@@ -306,13 +304,9 @@ int rg_launch_igemm2(const CL5& X, const CL5& Y, const void* w_packed, const flo
   if (nf % 9 == 0) fn = 9; else if (nf % 8 == 0) fn = 8; else if (nf <= 5) fn = nf < 4 ? 4 : nf; else if (nf % 5 == 0) fn = 5;
   else fn = (round_up(nf, 9) - nf) * 8 <= (round_up(nf, 8) - nf) * 9 ? 9 : 8;
   // rows per tile: 256 unless that leaves the 256 CUs with fewer than ~2 rounds of workgroups
-  const long tiles256 = ((a.M + 255) / 256) * ((nf + fn - 1) / fn);
-  const char* eb = getenv("RG_BIG");
   // BM = 128 at two workgroups per CU (TLP hides the stage hand-over) measured faster than BM = 256 at one: 715-750
-  // vs 460-540 TFLOP/s on the 432..3024-channel layers; the 256-row variant is kept for experiments (RG_BIG=1).
-  const bool big = eb ? atoi(eb) != 0 : false;
-  (void)tiles256;
-#define RG_L2(FN_) do { if (big) launch_igemm2<256, FN_>(a, st); else launch_igemm2<128, FN_>(a, st); } while (0)
+  // vs 460-540 TFLOP/s on the 432..3024-channel layers
+#define RG_L2(FN_) launch_igemm2<128, FN_>(a, st)
   switch (fn) {
     case 4: RG_L2(4); break;
     case 5: RG_L2(5); break;

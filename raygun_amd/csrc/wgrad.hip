@@ -616,7 +616,7 @@ static bool wgrad_lines_ok(const CL5& G, const CL5& X, const rg_conv_params* p, 
 // bottleneck: measured 4.3 of 5.0 ms with the MFMAs removed), so every piece's byte offset inside its line/plane is a
 // per-thread constant, the per-step part is wave-uniform (SGPR base in a buffer descriptor whose num_records does the
 // bounds check: out-of-range rows read as zero), and the unit -> (n, d, h, chunk) decode is incremental.
-struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; int flat; unsigned pmagic; int exp; };
+struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; int flat; unsigned pmagic; };
 
 template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP>
 __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
@@ -767,8 +767,8 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
     for (long u = ubeg; u < uend; ++u, buf ^= 1) {
       lstore(r0, buf);
       __syncthreads();
-      if (u + 1 < uend && !(p.exp & 1)) gload(r0);
-      if (!(p.exp & 2)) compute(buf);
+      if (u + 1 < uend) gload(r0);
+      compute(buf);
     }
   }
 
@@ -939,12 +939,12 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
     for (long u = ubeg; u < uend; u += 2) {
       pbar();
       wg_wait_loads<PER_P>(regsA);                             // unit u+1 landed (unit u+2 may still fly)
-      if (u + 1 < uend && !(p.exp & 16)) lstore(regsA, 1);
+      if (u + 1 < uend) lstore(regsA, 1);
       gload(regsA);                                            // unit u+3
       if (u + 1 < uend) {
         pbar();
         wg_wait_loads<PER_P>(regsB);                           // unit u+2
-        if (u + 2 < uend && !(p.exp & 16)) lstore(regsB, 0);
+        if (u + 2 < uend) lstore(regsB, 0);
         gload(regsB);                                          // unit u+4
       }
     }
@@ -968,7 +968,6 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (p.exp & 2) continue;
     bf16x8 gf[IA];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
@@ -1238,7 +1237,6 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     ka.pmagic = (unsigned)((1ULL << 32) / (unsigned)X.W + 1);
     ka.units_per_split = rps;
     ka.nta = (a.A + fa * 16 - 1) / (fa * 16); ka.ntb = (a.B + fb * 16 - 1) / (fb * 16);
-    { const char* e = getenv("RG_EXP"); ka.exp = e ? atoi(e) : 0; }
     dim3 grid(ka.nta * ka.ntb, a.TD * a.TH, ns);
     rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
     if (kind == 1 && !getenv("RG_NO_KWP")) {
