@@ -159,3 +159,39 @@ def test_train_step_config1_as_specified_running_stats():
     assert all(torch.equal(m.running_mean, b0) for m, b0 in zip(norms, before))       # eval mode does not update them
     assert float((y - y_train).abs().max()) <= 3e-2 * float(y_train.abs().max())
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+
+
+def test_cycle_model_crop_pad_and_sampling_bottleneck():
+    """CycleModel.forward's optional stages (reference models/CycleModel.py:24-30,45-46: off in every BASELINE config, on when the two
+    volumes' voxel sizes differ): the fake image is cropped by `crop_pad` and passed through the trilinear down / up "sampling
+    bottleneck" (align_corners=True) before the second generator — against the same composition written out with the CPU oracle's
+    generators."""
+    import torch.nn.functional as F
+    from oracle import torch_ref as O
+    from raygun_amd.torch.models import CycleModel
+    from raygun_amd.torch.networks import ResNet
+    IN = functools.partial(torch.nn.InstanceNorm3d)
+    kw = dict(input_nc=1, output_nc=1, ngf=8, n_blocks=1, n_downsampling=1, norm_layer=IN, padding_type="same")
+    g1, g2, r1, r2 = ResNet(3, **kw), ResNet(3, **kw), O.ResNet(3, **kw), O.ResNet(3, **kw)
+    for i, (a, b) in enumerate(((g1, r1), (g2, r2))):
+        sd = synth.fill_state_dict(a.state_dict(), 120 + i)
+        a.load_state_dict(sd); b.load_state_dict(sd)
+    dev = torch.device("cuda")
+    m = CycleModel(g1.to(dev), g2.to(dev), scale_factor_A=(0.5, 0.5, 0.5), scale_factor_B=(0.75, 0.5, 0.5))
+    m.set_crop_pad(2, 3)
+    xa = torch.from_numpy(synth.uniform((1, 1, 24, 24, 24), 130)); xb = torch.from_numpy(synth.uniform((1, 1, 24, 24, 24), 131))
+    fake_B, cycled_B, fake_A, cycled_A = m(real_A=xa.to(dev), real_B=xb.to(dev))
+    crop = (slice(None),) * 2 + (slice(2, -2),) * 3
+
+    def ref_direction(x, na, nb, sf):
+        with torch.no_grad():
+            fake = na(x)[crop]
+            size = fake.shape[-3:]
+            fake = F.interpolate(F.interpolate(fake, scale_factor=sf, mode="trilinear", align_corners=True), size=size, mode="trilinear", align_corners=True)
+            return fake, nb(fake)[crop]
+    rfB, rcA = ref_direction(xa, r1, r2, (0.75, 0.5, 0.5))
+    rfA, rcB = ref_direction(xb, r2, r1, (0.5, 0.5, 0.5))
+    l2 = lambda a, b: float((a.detach().float().cpu() - b).norm() / b.norm())  # noqa: E731
+    assert tuple(fake_B.shape) == tuple(rfB.shape) == (1, 1, 20, 20, 20) and tuple(cycled_A.shape) == tuple(rcA.shape) == (1, 1, 16, 16, 16)
+    errs = dict(fake_B=l2(fake_B, rfB), cycled_A=l2(cycled_A, rcA), fake_A=l2(fake_A, rfA), cycled_B=l2(cycled_B, rcB))
+    assert errs["fake_A"] <= 3e-2 and errs["fake_B"] <= 3e-2 and errs["cycled_A"] <= 5e-2 and errs["cycled_B"] <= 5e-2, errs  # bf16 policy; cycled = two generators
