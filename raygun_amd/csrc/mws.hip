@@ -208,15 +208,22 @@ __device__ __forceinline__ void mws_list_append(const MwsState& s, int r, int h,
 }
 
 // Grid barrier of the persistent kernel.  One thread per workgroup does the device-scope release / acquire (the workgroup
-// barriers around it order the other waves' accesses with it); measured on MI355X: 2.2 us at 32 workgroups, 3.7 us at 64,
-// 8.5 us at 128 — and 62 us at 128 when every wave fences, so the grid stays small: rounds are latency-bound.
-__device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target, unsigned nwg) {
+// barriers around it order the other waves' accesses with it).  The arrivals are counted in a two-level tree — groups of 16
+// workgroups on counters of their own (64 bytes apart), the last arriver of a group bumps the top counter everybody polls —
+// because 128 atomic increments of ONE word serialise: measured on MI355X with a flat counter 2.2 us at 32 workgroups, 3.7 us
+// at 64, 8.5 us at 128 (and 62 us at 128 when every wave fences, so the grid stays small: rounds are latency-bound).
+// Counters only ever grow (epoch e is complete when the top counter reaches e * groups): no reset, no ABA.
+#define MWS_BAR_GROUP 16
+#define MWS_BAR_STRIDE 16   // unsigned words between counters
+__device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& epoch, unsigned nwg) {
   __syncthreads();
-  target += nwg;
+  ++epoch;
   if (threadIdx.x == 0) {
     __threadfence();
-    atomicAdd(bar, 1u);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    const unsigned g = blockIdx.x / MWS_BAR_GROUP, ng = (nwg + MWS_BAR_GROUP - 1) / MWS_BAR_GROUP;
+    const unsigned gsize = (g + 1) * MWS_BAR_GROUP <= nwg ? MWS_BAR_GROUP : nwg - g * MWS_BAR_GROUP;
+    if (atomicAdd(&bar[(1 + g) * MWS_BAR_STRIDE], 1u) + 1 == epoch * gsize) atomicAdd(&bar[0], 1u);   // last of my group this epoch
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * ng) __builtin_amdgcn_s_sleep(1);
     __threadfence();
   }
   __syncthreads();
@@ -225,7 +232,7 @@ __device__ __forceinline__ void mws_grid_barrier(unsigned* bar, unsigned& target
 __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys, const unsigned* count, const int* offsets, MwsState s,
                                                                 u64* claim, u64* pairs, uint4* win0, uint4* win1, int2* ops, MwsCtl* ctl,
                                                                 int Z, int Y, int X, int n_off, int n_attr, unsigned cap, unsigned pool_cap, unsigned wmul,
-                                                                const unsigned* perm, const unsigned* eu, const unsigned* ev, const unsigned char* eattr) {
+                                                                const unsigned* perm, const unsigned* eu, const unsigned* ev, const unsigned char* eattr, unsigned* bar) {
   // grid mode (perm == nullptr): edge id = k*N + u on the (Z,Y,X) grid, v = u + offset k.  graph mode: slot -> edge perm[slot] of an
   // explicit edge list (eu, ev, eattr) over N = Z*Y*X abstract nodes (the second level of the slab decomposition).
   __shared__ int lin[64];
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       if (retired) e.x = MWS_RETIRED;
       win[i] = e;
     }
-    mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
+    mws_grid_barrier(bar, bar_target, gridDim.x);
     const u64 c1 = wall_clock64();
     // ---- phase B
     unsigned* surv = &ctl->surv[round & 1];
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
         if (op.x >= 0) ops_w[base + __popcll(om & ((1ull << lane) - 1ull))] = op;
       }
     }
-    mws_grid_barrier(&ctl->bar, bar_target, gridDim.x);
+    mws_grid_barrier(bar, bar_target, gridDim.x);
     const u64 c2 = wall_clock64();
     const unsigned ns2 = __hip_atomic_load(surv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned no = __hip_atomic_load(nops, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -406,7 +413,7 @@ static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
   size_t o = 0;
   o += al((size_t)q->ne_max * 8); q->off_keys2 = o;
   o += al((size_t)q->ne_max * 8); q->off_cnt = o;
-  o += 256; q->off_state = o;
+  o += 2048; q->off_state = o;   // edge count (+0), MwsCtl (+64), barrier counters (+512: 1 + MWS_MAX_WGS / 16 words, 64 B apart)
   o += al((size_t)q->N * 4) * 5; q->off_pool = o;
   q->pool_nodes = 2 * grid * (p->n_offsets - p->n_attractive) + 2;
   o += al((size_t)q->pool_nodes * 8); q->off_claim = o;
@@ -448,7 +455,7 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
   void* tmp = w + q.off_tmp;
   const int Z = p->shape[0], Y = p->shape[1], X = p->shape[2];
   int blocks = (int)((q.N + 255) / 256); if (blocks > 8192) blocks = 8192;
-  if (hipMemsetAsync(keys, 0xff, (size_t)q.ne_max * 8, st) != hipSuccess || hipMemsetAsync(count, 0, 256, st) != hipSuccess)
+  if (hipMemsetAsync(keys, 0xff, (size_t)q.ne_max * 8, st) != hipSuccess || hipMemsetAsync(count, 0, 2048, st) != hipSuccess)
     RG_FAIL(RG_ERR_HIP, "mws: memset failed");
   hipLaunchKernelGGL(mws_init_kernel, dim3(blocks), dim3(256), 0, st, S, first, flags, q.N);
   RG_CHECK_LAUNCH();
@@ -474,12 +481,13 @@ extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const u
     u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
     uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
     MwsCtl* ctl = (MwsCtl*)(w + q.off_cnt + 64);
+    unsigned* bar = (unsigned*)(w + q.off_cnt + 512);
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess || hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws: memset failed");
     const unsigned* gperm = nullptr; const unsigned* geu = nullptr; const unsigned* gev = nullptr; const unsigned char* gattr = nullptr;
     void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul,
-                    &gperm, &geu, &gev, &gattr};
+                    &gperm, &geu, &gev, &gattr, &bar};
     rg_set_kernel_name("mws_rounds_kernel");
     rg_prof_mark(st);
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
@@ -550,7 +558,7 @@ static int mws_graph_plan(int64_t n_nodes, int64_t n_edges, MwsGraphPlan* q) {
   q->off_win = o; o += 2 * al((size_t)MWS_WIN_CAP * 16);
   q->off_first = o; o += al((size_t)q->N * 4);
   q->off_flags = o; o += al((size_t)q->N * 4);
-  q->off_ctl = o; o += 512;
+  q->off_ctl = o; o += 2048;
   q->off_tmp = o; o += al(q->tmp_bytes);
   q->total = o;
   return 0;
@@ -582,7 +590,7 @@ extern "C" int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uin
   void* tmp = w + q.off_tmp;
   int blocks = (int)((q.N + 255) / 256); if (blocks > 8192) blocks = 8192;
   int eblocks = (int)((q.E + 255) / 256); if (eblocks > 8192) eblocks = 8192;
-  if (hipMemsetAsync(w + q.off_ctl, 0, 512, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");
+  if (hipMemsetAsync(w + q.off_ctl, 0, 2048, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");
   hipLaunchKernelGGL(mws_init_kernel, dim3(blocks), dim3(256), 0, st, S, first, flags, q.N);
   RG_CHECK_LAUNCH();
   if (n_edges > 0) {
@@ -608,13 +616,14 @@ extern "C" int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uin
     const u64* kp = nullptr; const unsigned* cp = count; const int* op = nullptr;
     u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
     uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
+    unsigned* bar = (unsigned*)(w + q.off_ctl + 512);
     int zz = 1, yy = 1, xx = (int)q.N, no = 0, na = 0;
     unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
     const unsigned* gperm = perm; const unsigned* geu = eu; const unsigned* gev = ev; const unsigned char* gattr = attractive;
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess ||
         hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");
     void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul,
-                    &gperm, &geu, &gev, &gattr};
+                    &gperm, &geu, &gev, &gattr, &bar};
     rg_set_kernel_name("mws_rounds_kernel(graph)");
     if (hipLaunchCooperativeKernel((const void*)mws_rounds_kernel, dim3(wgs), dim3(MWS_THREADS), args, 0, st) != hipSuccess)
       RG_FAIL(RG_ERR_HIP, "mws_graph: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
