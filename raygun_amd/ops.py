@@ -435,6 +435,14 @@ def _wino_ok(weight, stride, padding, dw_swapped, backward=False):
             and (is_cl_weight(weight) or weight.is_contiguous()))
 
 
+def _wino_fits(n, out_spatial, k, nout):
+    """The batched GEMM addresses one transform position's operands with 32-bit byte offsets (< 1 GiB each)."""
+    nt = n
+    for o in out_spatial:
+        nt *= (int(o) + 1) // 2
+    return nt * max(int(_L().rg_wino_weights_red(k)), int(_L().rg_wino_weights_red(nout))) * 2 < (1 << 30) and nt < (1 << 31)
+
+
 def _wino_weights(weight):
     """(U, Ut): G g G^T of the fp32 master weight as the forward and the backward-data GEMM operand; cached like the packed
     operands (per tensor version, dropped by FusedAdam / invalidate_packed)."""
@@ -660,8 +668,8 @@ class _Conv3d(Function):
                                f"Kernel size: {K}. Kernel size can't be greater than actual input size")
         y = alloc(n, cout, *O, x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
-        ctx.wino = _wino_ok(weight, stride, padding, dw_swapped, backward=True)
-        if _wino_ok(weight, stride, padding, dw_swapped):
+        ctx.wino = _wino_ok(weight, stride, padding, dw_swapped, backward=True) and _wino_fits(n, (D, H, W), cout, cin)
+        if _wino_ok(weight, stride, padding, dw_swapped) and _wino_fits(n, O, cin, cout):
             _wino_conv(x, _wino_weights(weight)[0], b, act, slope, y, 0)
         else:
             wp = pack_weights(weight, swap=0)
