@@ -234,7 +234,8 @@ typedef struct {
 } rg_mws_params;
 int64_t rg_mws_workspace_bytes(const rg_mws_params* p);
 /* affs: float32 (n_offsets,Z,Y,X) already in "edge weight" form (segment.py:191-194); offsets int32 (n_offsets,3);
- * mask: uint8 (Z,Y,X) or NULL; labels: uint64 (Z,Y,X). */
+ * mask: uint8 (Z,Y,X) or NULL; labels: uint64 (Z,Y,X).  * The call waits for the stream once (the edge count sizes the radix sort).
+ */
 int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels,
                    const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s);
 /* Diagnostics of the last rg_mws_segment run that used `workspace`: out = {edges, rounds, window visits, 100-MHz ticks in phase
