@@ -371,9 +371,16 @@ def mutex_segment(config_path, affs=None):
 
 
 def segment(config_path=None, affs=None):
-    """segment.py:233-296 — only the mutex branch is built."""
+    """segment.py:233-296 — only the mutex branch is built.  `python -m raygun_amd.segment seg.json` = raygun-segment."""
+    if config_path is None:
+        import sys
+        config_path = sys.argv[1]
     cfg = read_config(config_path)
     if cfg.get("mutex", False):
         return mutex_segment(config_path, affs=affs)
     raise NotImplementedError("raygun_amd.segment: the seeded-watershed + waterz branch (segment.py:250-296) is out of "
                               "scope; set \"mutex\": true")
+
+
+if __name__ == "__main__":
+    segment()
