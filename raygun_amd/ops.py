@@ -373,6 +373,16 @@ profile_shapes = False  # True: key the records by kernel name AND problem shape
 _event_pool, _event_next = [], 0  # timing events are reused across profile sessions: creating two per launch cost more host time than the launch
 
 
+def _drop_events():   # at interpreter exit, while torch's HIP context still exists (module globals are torn down in arbitrary order)
+    global _event_next
+    _event_pool.clear()
+    _event_next = 0
+
+
+import atexit  # noqa: E402
+atexit.register(_drop_events)
+
+
 def _event():
     global _event_next
     if _event_next == len(_event_pool):
