@@ -123,46 +123,56 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         from concurrent.futures import ThreadPoolExecutor
         reader = ThreadPoolExecutor(max_workers=1)
         ahead = reader.submit(fetch, mine[0])
-    for k, bi in enumerate(mine):
-        wz, wy, wx = blocks[bi]
-        rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
-        if resident:
-            blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
-        else:
-            host = ahead.result()
-            ahead = reader.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
-            blk = host.to(dev, non_blocking=True)[None, None]
-        if blk.dtype not in (torch.uint8,):
-            blk = blk.float()
-        x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
-        outs = model(x)
-        if not isinstance(outs, (tuple, list)):
-            outs = (outs,)
-        if destinations is None:
-            destinations = []
-            for i, o in enumerate(outs):
-                c = o.shape[1]
-                dt = np.float32 if out_dtypes is None else out_dtypes[i]
-                shp = ((c,) if c > 1 else ()) + tuple(source.shape)
-                destinations.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
-        out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in destinations}
-        for o, dest in zip(outs, destinations):
-            o = o.detach().float()[0]
-            if crop and crop != 0 and input_shape is None:
-                o = o[..., crop:-crop, crop:-crop, crop:-crop]
-            if tuple(o.shape[-3:]) != tuple(write):
-                off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
-                o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
+    try:
+        for k, bi in enumerate(mine):
+            wz, wy, wx = blocks[bi]
+            rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
             if resident:
-                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
-            elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
-                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
-            else:  # convert on the GPU, then let the drain thread download and scatter while the next block computes
-                if drain is None:
-                    drain = _Drain(dev)
-                drain.put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
-                          (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
-        n_done += 1
+                blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
+            else:
+                host = ahead.result()
+                ahead = reader.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
+                blk = host.to(dev, non_blocking=True)[None, None]
+            if blk.dtype not in (torch.uint8,):
+                blk = blk.float()
+            x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
+            outs = model(x)
+            if not isinstance(outs, (tuple, list)):
+                outs = (outs,)
+            if destinations is None:
+                destinations = []
+                for i, o in enumerate(outs):
+                    c = o.shape[1]
+                    dt = np.float32 if out_dtypes is None else out_dtypes[i]
+                    shp = ((c,) if c > 1 else ()) + tuple(source.shape)
+                    destinations.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
+            out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in destinations}
+            for o, dest in zip(outs, destinations):
+                o = o.detach().float()[0]
+                if crop and crop != 0 and input_shape is None:
+                    o = o[..., crop:-crop, crop:-crop, crop:-crop]
+                if tuple(o.shape[-3:]) != tuple(write):
+                    off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
+                    o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
+                if resident:
+                    dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
+                elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
+                    dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
+                else:  # convert on the GPU, then let the drain thread download and scatter while the next block computes
+                    if drain is None:
+                        drain = _Drain(dev)
+                    drain.put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
+                              (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
+            n_done += 1
+    except BaseException:  # a failing block must not leave the download / prefetch threads behind
+        if drain is not None:
+            try:
+                drain.close()
+            except BaseException:
+                pass
+        if not resident and len(mine):
+            reader.shutdown(wait=False)
+        raise
     if drain is not None:
         drain.close()
     if not resident and len(mine):
