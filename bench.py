@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--secondary-dp", action="store_true", help="with --gpus N > 1: time the CycleGAN step data-parallel as well (default: N = 1 only, "
                     "so that the scaling runs carry one workload and one set of collectives)")
     ap.add_argument("--cpu-size", type=int, default=0)
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N without a launcher: seconds before the supervised ranks are terminated")
     return ap.parse_args()
 
 
@@ -148,11 +149,47 @@ def pmc_traffic(kernel_name, tag="unet"):
     return out["fetch"] + out["write"]
 
 
+def host_cpu():
+    """(threads to use, description): the physical cores this process may run on (affinity mask / SMT siblings) and the CPU model."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    phys = avail
+    try:
+        import psutil
+        lp, pp = psutil.cpu_count(logical=True) or avail, psutil.cpu_count(logical=False) or avail
+        phys = max(1, min(avail, avail * pp // lp if avail == lp else avail))   # a restricted mask (container share) is taken as given
+    except Exception:
+        pass
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return phys, f"{model}, {phys} of {os.cpu_count()} hardware threads used"
+
+
+def timed_median(fn, budget_s=45.0, reps=3):
+    """1 warm-up call + up to `reps` timed calls of fn, bounded by `budget_s` of wall time: returns (median s,
+    calls timed, warm-up s).  A warm-up that alone exceeds the budget is the measurement."""
+    import statistics
+    t0 = time.time(); fn(); warm = time.time() - t0
+    ts = []
+    while len(ts) < reps and (time.time() - t0) + (ts[-1] if ts else warm) <= budget_s:
+        t1 = time.time(); fn(); ts.append(time.time() - t1)
+    return (statistics.median(ts), len(ts), warm) if ts else (warm, 0, warm)
+
+
 def cpu_baseline(workload, size):
-    """The oracle (plain PyTorch fp32 restatement) timed on this host's cores for one step on a bounded sample."""
+    """The oracle (plain PyTorch fp32 restatement) timed on this host's cores: one warm-up step + the median of up to 3 steps on
+    a bounded sample."""
     from oracle import torch_ref as O
     from raygun_amd import synth
-    cores = min(os.cpu_count() or 1, 16)
+    cores, cpu = host_cpu()
     torch.set_num_threads(cores)
     if workload == "unet":
         m = O.MTLSDModel()
@@ -162,21 +199,19 @@ def cpu_baseline(workload, size):
         ga = torch.from_numpy(synth.uniform((1, 3, out, out, out), 142, 0, 1))
         gl = torch.from_numpy(synth.uniform((1, 10, out, out, out), 242, 0, 1))
         opt = torch.optim.Adam(m.parameters(), lr=0.5e-4)
-        t0 = time.time()
-        O.mtlsd_step(m, lf, opt, raw, gl, torch.ones_like(gl), ga, torch.ones_like(ga))
-        dt = time.time() - t0
-        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
-                    sample=f"1 step (fwd+loss+bwd+Adam) of the CPU restatement at {size}^3 (torch {torch.__version__} fp32, oneDNN), {dt:.1f} s")
+        dt, n, warm = timed_median(lambda: O.mtlsd_step(m, lf, opt, raw, gl, torch.ones_like(gl), ga, torch.ones_like(ga)), budget_s=60.0)
+        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port", cpu=cpu,
+                    sample=f"train step (fwd+loss+bwd+Adam) of the CPU restatement at {size}^3 (torch {torch.__version__} fp32, oneDNN): "
+                           f"1 warm-up step ({warm:.1f} s) + median of {n} steps = {dt:.1f} s")
     import functools
     IN3 = functools.partial(torch.nn.InstanceNorm3d)
     model, loss, _ = O.build_cyclegan(3, dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same"),
                                       dict(input_nc=1, ngf=64, n_layers=3, kw=4), g_lr=1e-5, d_lr=1e-5, betas=(0.9, 0.999))
     A = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42)); B = torch.from_numpy(synth.uniform((1, 1, size, size, size), 1042))
-    t0 = time.time()
-    O.cyclegan_step(model, loss, A, B)
-    dt = time.time() - t0
-    return dict(value=dt * 1e3, unit="ms/step", cores=cores, kind="port",
-                sample=f"1 link train step of the CPU restatement at {size}^3 (work ratio to 128^3: {(128 / size) ** 3:.0f}x), {dt:.1f} s")
+    dt, n, warm = timed_median(lambda: O.cyclegan_step(model, loss, A, B), budget_s=45.0)
+    return dict(value=dt * 1e3, unit="ms/step", cores=cores, kind="port", cpu=cpu,
+                sample=f"link train step of the CPU restatement at {size}^3 (work ratio to 128^3: {(128 / size) ** 3:.0f}x): "
+                       f"1 warm-up ({warm:.1f} s) + median of {n} steps = {dt:.1f} s")
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -297,7 +332,8 @@ def main_aux(a, rank, local, world, dev):
         roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches_per_step=dom[1]["launches"] // a.steps,
                         avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
-        res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks", unit="Mvoxels/s", dtype="bf16",
+        res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks", unit="Mvoxels/s",
+                   dtype=os.environ.get("RAYGUN_AMD_PREDICT_PRECISION", "f16"),   # the block runner's 16-bit storage type (predict_volume's default: IEEE half)
                    config=dict(workload=f"predict {size}^3 uint8 volume per GPU in {nblk} blocks, MTLSDModel(UNet ngf12 x6 3-level valid, "
                                         "20 affinities + 10 LSDs), uint8 destinations in HBM", parallelism=f"one volume of {nblk} blocks per GPU x{world}"),
                    blocks_per_s=round(nblk * world / (dt / a.steps), 2))
@@ -315,7 +351,7 @@ def main_aux(a, rank, local, world, dev):
 
 def cpu_baseline_aux(workload, size):
     import numpy as np
-    cores = min(os.cpu_count() or 1, 16)
+    cores, cpu = host_cpu()
     torch.set_num_threads(cores)
     if workload == "segment":
         from oracle import mws as OM
@@ -325,38 +361,25 @@ def cpu_baseline_aux(workload, size):
         w, m = OM.prepare(affs)
         OM.compute_mws_segmentation(w, OM.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m)
         dt = time.time() - t0
-        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=1, kind="port",
+        return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=1, kind="port", cpu=cpu,
                     sample=f"numpy prepare + oracle/mws.c (sequential Kruskal, as affogato is single-threaded) on the same synthetic affinities at {size}^3, {dt:.1f} s")
     from oracle import torch_ref as O
     from raygun_amd import synth
     m = O.MTLSDModel(num_affs=20).eval()
     x = torch.from_numpy(synth.uniform((1, 1, 196, 196, 196), 42, 0, 1))
     with torch.no_grad():
-        t0 = time.time()
-        for _ in range(2):
-            m(x)
-        dt = (time.time() - t0) / 2
-    return dict(value=104 ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
-                sample=f"forward of the CPU restatement on 2 blocks of 196^3 (torch {torch.__version__} fp32, oneDNN), {dt:.1f} s per block")
+        dt, n, warm = timed_median(lambda: m(x), budget_s=30.0)
+    return dict(value=104 ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port", cpu=cpu,
+                sample=f"forward of the CPU restatement on one 196^3 block (torch {torch.__version__} fp32, oneDNN): 1 warm-up + median of {n} = {dt:.1f} s per block")
 
 
 def launch_ranks(a):
-    """`python bench.py --gpus N` without a launcher: start N rank processes (torchrun-style environment, rendezvous on
-    127.0.0.1, backend nccl = RCCL) from this parent, which has not touched the GPU.  Rank 0's stdout (the JSON line) is ours;
-    the other ranks' stdout goes to stderr.  Exit code: first non-zero child code."""
-    import socket
-    import subprocess
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
-    rc = 0
-    for p in procs:
-        rc = rc or p.wait()
-    return rc
+    """`python bench.py --gpus N` without a launcher: start N supervised rank processes (raygun_amd.parallel.launch_ranks:
+    torchrun-style environment, rendezvous on 127.0.0.1, backend nccl = RCCL) from this parent, which has not touched the GPU.
+    Rank 0's stdout (the JSON line) is ours; a failing rank or the overall timeout (--rank-timeout, default 900 s) ends all ranks
+    and the exit code is non-zero."""
+    from raygun_amd.parallel import launch_ranks as launch
+    return launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.rank_timeout)
 
 
 def run_train(a, workload, size, steps, warmup, rank, world, dev):

@@ -54,6 +54,14 @@ int rg_profile_drain(float* ms, int cap);
 const char* rg_last_error_string(void);
 /* name (template instantiation) of the main kernel launched by this thread's last conv/wgrad call — profiling aid */
 const char* rg_last_kernel_name(void);
+/* Diagnostic switches (0 = production default): "RG_FM" (forced igemm4 tile height 1..4), "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3",
+ * "RG_NO_WLINES", "RG_NO_KWP" (kernel families switched off: the launch falls through to the next candidate), "RG_DEBUG_BOUNDS"
+ * (every entry point re-derives the byte extent its kernels may touch from the descriptors and fails with RG_ERR_BAD_SHAPE instead
+ * of launching when a workspace / packed operand / view is smaller).  The environment variables of the same names are read ONCE,
+ * when the library is loaded; no launch path reads the environment.  Process-wide. */
+int rg_hip_status(void);   /* 0, or the hipError_t pending on this thread (a failed kernel launch is otherwise silent); sets the error string */
+int rg_set_option(const char* name, int32_t value);
+int32_t rg_get_option(const char* name);   /* -1: unknown name */
 
 /* ---- layout conversion (torch .to(memory_format)/.float() around the nets: torch/predict/worker.py:101-110,146-149)
  * src: any dtype in {bf16,f32,u8}, any strides.  dst: bf16 or f32, any strides.  dst_lanes >= C: channel lanes
@@ -124,6 +132,7 @@ int rg_wino_weights(const void* w_f32, int32_t channels_last, int32_t cout, int3
 int rg_wino_input(const rg_tensor* x, void* V, int64_t v_cstride, const int32_t tiles[3], const int32_t origin[3], rg_stream s);
 int rg_wino_output(const void* M, int64_t m_cstride, const int32_t tiles[3], rg_tensor* y, const float* bias, int32_t cout,
                    int32_t act, float slope, rg_stream s);
+int32_t rg_gemm_batched_tile_n(int32_t n);   /* 8 | 9 (x 16 columns) or 0: rg_gemm_batched refuses this n — host logic, no GPU call */
 int rg_gemm_batched(const void* A, const void* W, void* C, int64_t batches, int64_t m, int32_t k, int32_t n, int64_t a_row_stride,
                     int64_t a_batch_stride, int64_t w_batch_stride, int64_t c_row_stride, int64_t c_batch_stride, rg_stream s);
 

@@ -7,6 +7,8 @@ networks/UNet.py:85,233,575).
 import ctypes as C
 import os
 
+from . import _debug
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libraygun_hip.so")
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "lib", "libraygun_hip_f16.so")}  # same sources, 16-bit storage type differs
@@ -44,6 +46,9 @@ _SIGS = {
     "rg_version": (C.c_int, []),
     "rg_last_error_string": (C.c_char_p, []),
     "rg_last_kernel_name": (C.c_char_p, []),
+    "rg_hip_status": (C.c_int, []),
+    "rg_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "rg_get_option": (C.c_int32, [C.c_char_p]),
     "rg_copy_convert": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "rg_conv3d_kalign": (C.c_int, [C.c_int, C.c_int]),
     "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),
@@ -56,6 +61,7 @@ _SIGS = {
     "rg_wino_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rg_wino_input": (C.c_int, [_T, C.c_void_p, C.c_int64, _I3, _I3, C.c_void_p]),
     "rg_wino_output": (C.c_int, [C.c_void_p, C.c_int64, _I3, _T, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "rg_gemm_batched_tile_n": (C.c_int32, [C.c_int32]),
     "rg_gemm_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "rg_conv3d_wgrad_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params), _P(C.c_int32)]),
@@ -138,11 +144,15 @@ _DEBUG_SYNC = bool(os.environ.get("RAYGUN_AMD_DEBUG_SYNC"))  # fault localisatio
 
 
 def check(rc, what=""):
+    if _debug.ON:
+        _debug.verify(f"{what} ({lib(getattr(_tls, 'last', 'bf16')).rg_last_kernel_name().decode()})")
     if _DEBUG_SYNC:
         import sys
         import torch
         sys.stderr.write(f"[rg] {what} {lib(getattr(_tls, 'last', 'bf16')).rg_last_kernel_name().decode()}\n"); sys.stderr.flush()
         torch.cuda.synchronize()
+    if rc == 0:
+        rc = lib(getattr(_tls, "last", "bf16")).rg_hip_status()   # a kernel launch that failed (bad configuration, LDS size, ...) is silent otherwise
     if rc != 0:
         msg = lib(getattr(_tls, "last", "bf16")).rg_last_error_string().decode("utf-8", "replace")
         raise RuntimeError(f"raygun_amd HIP call failed ({what}, status {rc}): {msg}")

@@ -17,6 +17,15 @@ typedef unsigned short bf16_t;
 void rg_set_error(const char* fmt, ...);
 void rg_set_kernel_name(const char* fmt, ...);  // name of the dominant kernel of the last call (profiling aid)
 void rg_prof_mark(hipStream_t st);              // HIP event before / after the dominant kernel when rg_profile_enable(1)
+// Diagnostic switches (rg_set_option / the RG_* environment variables read ONCE when the library is loaded — never in a launch path).
+// 0 = production default everywhere.
+enum { RG_OPT_FM = 0, RG_OPT_NO_HALO, RG_OPT_NO_THIN, RG_OPT_NO_THIN3, RG_OPT_NO_WLINES, RG_OPT_NO_KWP, RG_OPT_DEBUG_BOUNDS, RG_OPT_COUNT };
+int rg_opt(int which);
+// "once per device" latch for hipFuncSetAttribute (a function attribute belongs to the device that was current when it was set):
+// `fn` runs exactly once per (latch, current device), under the latch lock: a second host thread (autograd's) launching the same
+// kernel waits until the attribute is set.
+struct rg_device_latch { unsigned long long done[4] = {0, 0, 0, 0}; };
+void rg_once_per_device(rg_device_latch* l, void (*fn)());
 #define RG_FAIL(code, ...) do { rg_set_error(__VA_ARGS__); return (code); } while (0)
 #define RG_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
   rg_set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return RG_ERR_HIP; } } while (0)
@@ -50,7 +59,7 @@ __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
   // switch cost more than a thin layer's MFMAs, see conv5.hip); the two transcendental ones behind one wave-uniform branch
   if (act <= RG_ACT_LEAKY) {
     const float neg = act == RG_ACT_RELU ? 0.f : v * (act == RG_ACT_LEAKY ? slope : 1.f);
-    return v > 0.f ? v : neg;
+    return v < 0.f ? neg : v;   // (this form hands a NaN on, like torch.relu; `v > 0 ? v : neg` would turn it into 0 and hide an overflow)
   }
   return act == RG_ACT_SIGMOID ? 1.f / (1.f + __expf(-v)) : tanhf(v);
 }

@@ -429,6 +429,13 @@ bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p) {
   return cl5_extent(X) * 2 < (1L << 30) && wel * 2 < (1L << 30);
 }
 int rg_igemm4_tile_n(int cout) { return ig4_fn(round_up(cout, 16) / 16); }
+// Column tile of rg_gemm_batched for n columns, in 16-column fragments (8 = 128, 9 = 144 columns), or 0 when n has no such
+// tiling and the call would be refused (n = 145..160, 305..320, ...): callers pick another path BEFORE transforming operands.
+extern "C" int32_t rg_gemm_batched_tile_n(int32_t n) {
+  if (n <= 0) return 0;
+  const int fn = ig4_fn(round_up(n, 16) / 16);
+  return fn < 8 ? 0 : fn;
+}
 
 bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
@@ -475,8 +482,8 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
-  if (flat && rg_halo16_ok(X, Y, p) && !getenv("RG_NO_HALO")) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
-  if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !getenv("RG_NO_THIN")) return rg_launch_igemm_thin(a, check, st);
+  if (flat && rg_halo16_ok(X, Y, p) && !rg_opt(RG_OPT_NO_HALO)) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
+  if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !rg_opt(RG_OPT_NO_THIN)) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;
   const int fn = flat ? (nf <= 6 ? nf : (nf == 7 ? 8 : ig4_fn(nf))) : ig4_fn(nf);
   // rows per tile: 256 (FM = 4, two workgroups per CU, weight-fragment reads amortised over 4 row fragments: ~1000-1060
@@ -486,8 +493,8 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   const long b2 = ((a.M + 127) / 128) * ntn * a.nbatch, b4 = ((a.M + 255) / 256) * ntn * a.nbatch;
   const double e2 = b2 <= 768 ? b2 / 768.0 : 0.5 + 0.5 * b2 / (double)((b2 + 767) / 768 * 768);  // co-resident workgroups speed up when a CU is not full
   const double e4 = b4 <= 512 ? b4 / 512.0 : b4 / (double)((b4 + 511) / 512 * 512);
-  const char* e = getenv("RG_FM");
-  int fm = e ? atoi(e) : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
+  const int e = rg_opt(RG_OPT_FM);   // forced tile height (diagnostics / tests), 0 = the heuristic
+  int fm = e ? e : (1030.0 * e4 > 880.0 * e2 ? 4 : 2);
   // 192-row tiles (FM = 3, 144-channel tiles only) for grids that leave the last round of 256- and 128-row tiles half empty
   // (2592 -> 2592 at 17^3: 360 / 468 / 702 tiles -> 821 TFLOP/s with FM = 2, 887 with FM = 3); never for grids below one tile per CU
   if (!e && (fn == 9 || fn == 8) && a.rs[0] == 1 && a.rs[1] == 1 && a.rs[2] == 1) {  // (strided gathers measured slower with 192 rows)
@@ -817,30 +824,28 @@ int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st) {
   // persistent workgroups: as many as fit the CUs (LDS-limited), every one stages the weights once
   int per_cu = (int)((160 * 1024) / (shm + 1024)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
   int grid = 256 * per_cu; if (grid > a.tiles_m) grid = a.tiles_m;
-  if (a.TW == 3 && (a.ts[2] == 1 || a.ts[2] == -1) && a.rs[2] == 1 && a.cp >= 4 && !getenv("RG_NO_THIN3")) {
+  if (a.TW == 3 && (a.ts[2] == 1 || a.ts[2] == -1) && a.rs[2] == 1 && a.cp >= 4 && !rg_opt(RG_OPT_NO_THIN3)) {
     const size_t shm3 = (size_t)a.krow * 32 + (size_t)((a.TD * a.TH * a.cp + 3) / 4 + 2) * 64 + (size_t)16 * FM * 20 * 16;
     const long nfrag = (long)a.N * a.RD * a.RH * ((a.RW + 15) / 16);
     a.tiles_m = (int)((nfrag + 4 * FM - 1) / (4 * FM));
     int pc = (int)((160 * 1024) / (shm3 + 1024)); if (pc > 8) pc = 8; if (pc < 1) pc = 1;
     int grid3 = 256 * pc; if (grid3 > a.tiles_m) grid3 = a.tiles_m;
     rg_set_kernel_name("igemm_thin3_kernel<%d,%d>", FM, (int)check);
-    static bool attr3_done = false;
-    if (!attr3_done) {
-      hipFuncSetAttribute((const void*)igemm_thin3_kernel<FM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-      hipFuncSetAttribute((const void*)igemm_thin3_kernel<FM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-      attr3_done = true;
-    }
+    static rg_device_latch attr3;
+    rg_once_per_device(&attr3, [] {
+      hipFuncSetAttribute((const void*)igemm_thin3_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      hipFuncSetAttribute((const void*)igemm_thin3_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    });
     if (check) hipLaunchKernelGGL((igemm_thin3_kernel<FM, true>), dim3(grid3), dim3(256), shm3, st, a);
     else hipLaunchKernelGGL((igemm_thin3_kernel<FM, false>), dim3(grid3), dim3(256), shm3, st, a);
     return RG_OK;
   }
   rg_set_kernel_name("igemm_thin_kernel<%d,%d>", FM, (int)check);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)igemm_thin_kernel<FM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    hipFuncSetAttribute((const void*)igemm_thin_kernel<FM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    attr_done = true;
-  }
+  static rg_device_latch attr1;
+  rg_once_per_device(&attr1, [] {
+    hipFuncSetAttribute((const void*)igemm_thin_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    hipFuncSetAttribute((const void*)igemm_thin_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  });
   if (check) hipLaunchKernelGGL((igemm_thin_kernel<FM, true>), dim3(grid), dim3(256), shm, st, a);
   else hipLaunchKernelGGL((igemm_thin_kernel<FM, false>), dim3(grid), dim3(256), shm, st, a);
   return RG_OK;

@@ -21,6 +21,45 @@ extern "C" int rg_version(void) { return 101 | (1 << 16); }  // bit 16: this bui
 extern "C" int rg_version(void) { return 101; }
 #endif
 
+// ---- diagnostic switches + per-device latches ------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS"};
+static std::atomic<int> g_opt[RG_OPT_COUNT];
+static const bool g_opt_init = [] {   // environment -> switches, once, when the library is loaded
+  for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? (i == RG_OPT_FM ? atoi(e) : (e[0] && e[0] != '0')) : 0); }
+  return true;
+}();
+int rg_opt(int which) { return which >= 0 && which < RG_OPT_COUNT ? g_opt[which].load(std::memory_order_relaxed) : 0; }
+extern "C" int rg_set_option(const char* name, int32_t value) {
+  for (int i = 0; name && i < RG_OPT_COUNT; ++i)
+    if (!strcmp(name, g_opt_names[i])) { g_opt[i].store(value); return RG_OK; }
+  RG_FAIL(RG_ERR_BAD_SHAPE, "rg_set_option: unknown option %s", name ? name : "(null)");
+}
+extern "C" int32_t rg_get_option(const char* name) {
+  for (int i = 0; name && i < RG_OPT_COUNT; ++i) if (!strcmp(name, g_opt_names[i])) return g_opt[i].load();
+  return -1;
+}
+// Launch errors are otherwise silent (hipLaunchKernelGGL returns nothing): the binding peeks at the runtime's sticky error after
+// every entry point and raises.  0 = no error pending; else the hipError_t, with rg_last_error_string() set.
+extern "C" int rg_hip_status(void) {
+  const hipError_t e = hipPeekAtLastError();
+  if (e == hipSuccess) return 0;
+  rg_set_error("HIP runtime error pending after %s: %s", g_kname[0] ? g_kname : "(no kernel)", hipGetErrorString(e));
+  return (int)e;
+}
+static std::mutex g_latch_mu;
+void rg_once_per_device(rg_device_latch* l, void (*fn)()) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) d = 0;
+  std::lock_guard<std::mutex> g(g_latch_mu);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (l->done[d >> 6] & bit) return;
+  fn();
+  l->done[d >> 6] |= bit;
+}
+
 // ---- kernel timing aid (bench.py's roofline): HIP events around the DOMINANT kernel of a call, on the launch stream -------
 // A weight-gradient call launches its main kernel plus small reduction passes; timing the whole call from outside would not
 // agree with rocprofv3's per-kernel average.  Off by default (no events, no overhead); not thread-safe (one profiling host

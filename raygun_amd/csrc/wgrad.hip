@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void wgrad_lines_kernel(WgradLinesArgs p) {
   }
 }
 static bool wgrad_lines_ok(const CL5& G, const CL5& X, const rg_conv_params* p, int fa, int fb) {
-  if (fa != 1 || fb != 1 || getenv("RG_NO_WLINES")) return false;
+  if (fa != 1 || fb != 1 || rg_opt(RG_OPT_NO_WLINES)) return false;
   if (wg_extent(X) * 2 >= (1L << 30) || wg_extent(G) * 2 >= (1L << 30)) return false;  // 32-bit byte offsets
   if (p->T[0] != 3 || p->T[1] != 3 || p->T[2] > 3) return false;
   const int I[3] = {X.D, X.H, X.W};
@@ -1239,16 +1239,16 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     ka.nta = (a.A + fa * 16 - 1) / (fa * 16); ka.ntb = (a.B + fb * 16 - 1) / (fb * 16);
     dim3 grid(ka.nta * ka.ntb, a.TD * a.TH, ns);
     rg_set_kernel_name("wgrad_kw_kernel<%d,%d>", fa, fb);
-    if (kind == 1 && !getenv("RG_NO_KWP")) {
+    if (kind == 1 && !rg_opt(RG_OPT_NO_KWP)) {
       rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
       hipLaunchKernelGGL((wgrad_kwp_kernel<9, 9, 3, 3, 3, 3>), grid, dim3(768), 0, st, ka);
     } else if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
     else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
-    else if (kind == 3 && a.TW <= 3 && !getenv("RG_NO_KWP")) {
+    else if (kind == 3 && a.TW <= 3 && !rg_opt(RG_OPT_NO_KWP)) {
       rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
       hipLaunchKernelGGL((wgrad_kwp_kernel<8, 8, 2, 4, 3, 4>), grid, dim3(768), 0, st, ka);
     } else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);
-    else if (kind == 4 && !getenv("RG_NO_KWP")) { rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb); hipLaunchKernelGGL((wgrad_kwp_kernel<5, 5, 5, 1, 3, 3>), grid, dim3(512), 0, st, ka); }
+    else if (kind == 4 && !rg_opt(RG_OPT_NO_KWP)) { rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb); hipLaunchKernelGGL((wgrad_kwp_kernel<5, 5, 5, 1, 3, 3>), grid, dim3(512), 0, st, ka); }
     else if (kind == 4) hipLaunchKernelGGL((wgrad_kw_kernel<5, 5, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
     else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
@@ -1263,8 +1263,9 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     la.units_per_split = rps;
     la.xbytes = (unsigned)(wg_extent(X) * 2); la.gbytes = (unsigned)(wg_extent(G) * 2);
     constexpr size_t shm = 2 * (size_t)(WB_LD * WB_LH * 32 + (WB_LD + 2) * (WB_LH + 2) * 34) * 16 * sizeof(bf16_t);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)wgrad_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_set = true; }
+    static rg_device_latch attr_lines;
+    rg_once_per_device(&attr_lines, [] { hipFuncSetAttribute((const void*)wgrad_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             (int)(2 * (size_t)(WB_LD * WB_LH * 32 + (WB_LD + 2) * (WB_LH + 2) * 34) * 16 * sizeof(bf16_t))); });
     rg_set_kernel_name("wgrad_lines_kernel");
     hipLaunchKernelGGL(wgrad_lines_kernel, dim3(1, 1, ns), dim3(256), shm, st, la);
   } else if (wgrad_line_ok(G, X, p, fa, fb)) {

@@ -14,7 +14,7 @@ import threading
 
 import torch
 
-from . import _lib
+from . import _debug, _lib
 from ._lib import ACT, i3, rg_conv_params, rg_pack_params, rg_tensor
 
 _DT = {torch.bfloat16: _lib.RG_BF16, torch.float32: _lib.RG_F32, torch.uint8: _lib.RG_U8,
@@ -48,6 +48,23 @@ def precision(kind):
 def _L():
     """The library of the current storage type."""
     return _lib.lib(_KIND[storage_dtype()])
+
+
+@contextlib.contextmanager
+def option(name, value):
+    """Set a diagnostic switch of BOTH libraries (include/raygun_hip.h rg_set_option: "RG_FM", "RG_NO_HALO", ...) for the enclosed
+    calls.  Process-wide, for tests and tools; production code never touches these."""
+    libs = [_lib.lib("bf16"), _lib.lib("f16")]
+    prev = [l.rg_get_option(name.encode()) for l in libs]
+    if min(prev) < 0:
+        raise KeyError(name)
+    for l in libs:
+        _lib.check(l.rg_set_option(name.encode(), int(value)), "rg_set_option")
+    try:
+        yield
+    finally:
+        for l, v in zip(libs, prev):
+            l.rg_set_option(name.encode(), v)
 
 
 def _first_half_dtype(args):
@@ -96,6 +113,8 @@ def _require_cuda(t, what):
 
 def desc(t):
     """rg_tensor descriptor of a torch tensor (rank <= 6)."""
+    if _debug.ON:
+        _debug.check_view(t, lanes_of(t.shape[1]) if t.dim() == 5 and t.dtype in _KIND else None)
     d = rg_tensor()
     d.ptr = t.data_ptr()
     d.dtype = _DT[t.dtype]
@@ -120,7 +139,7 @@ def voxel_stride_of(c):
 
 def cl_empty(n, c, d, h, w, device):
     """Uninitialised channels-last bf16 activation (every kernel writes all lanes incl. zero pad lanes)."""
-    buf = torch.empty((n, d, h, w, voxel_stride_of(c)), dtype=storage_dtype(), device=device)
+    buf = _debug.empty((n, d, h, w, voxel_stride_of(c)), storage_dtype(), device)
     return buf.permute(0, 4, 1, 2, 3)[:, :c]
 
 
@@ -176,7 +195,7 @@ as_cl = to_cl
 
 def from_cl(t, dtype=torch.float32):
     """channels-last bf16 -> dense NCDHW `dtype` (no autograd)."""
-    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    out = _debug.empty(t.shape, dtype, t.device)
     if t.numel():
         _lib.check(_lib.lib(_KIND[t.dtype]).rg_copy_convert(C.byref(desc(t)), C.byref(desc(out)), t.shape[1], 1.0, 0.0, _stream()),
                    "rg_copy_convert")
@@ -294,7 +313,7 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     nbytes = _L().rg_pack_weights_bytes(C.byref(p))
     if nbytes < 0:
         raise RuntimeError("raygun_amd.pack_weights: bad packing parameters")
-    out = torch.empty(nbytes // 2, dtype=storage_dtype(), device=w.device)
+    out = _debug.empty(nbytes // 2, storage_dtype(), w.device)
     _lib.check(_L().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
                "rg_pack_weights")
     cache[key] = out
@@ -420,7 +439,7 @@ def _igemm(x, wp, bias, y, p):
     bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
     dx, dy = desc(x), desc(y)
     nbytes = _L().rg_conv3d_igemm_workspace_bytes(C.byref(dx), C.byref(dy), C.byref(p))   # split-K partial sums of small-grid launches
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes > 0 else None
+    ws = _debug.empty(nbytes, torch.uint8, x.device) if nbytes > 0 else None
     _timed(_conv_flops(p, x.shape[0], x.shape[1], y.shape[1]),
            lambda: _lib.check(_L().rg_conv3d_igemm2(C.byref(dx), C.c_void_p(wp.data_ptr()), bptr, C.byref(dy), C.byref(p),
                                                     C.c_void_p(ws.data_ptr()) if ws is not None else None, max(nbytes, 0), _stream()),
@@ -442,7 +461,10 @@ def _wino_ok(weight, stride, padding, dw_swapped, backward=False):
     return (os.environ.get("RAYGUN_AMD_WINOGRAD", "1") != "0" and not dw_swapped
             and tuple(weight.shape[2:]) == (3, 3, 3) and tuple(stride) == (1, 1, 1) and tuple(padding) == (0, 0, 0)
             and red >= WINO_MIN_CHANNELS and cols >= min(128, WINO_MIN_CHANNELS) and weight.dtype == torch.float32
-            and (is_cl_weight(weight) or weight.is_contiguous()))
+            and (is_cl_weight(weight) or weight.is_contiguous())
+            # the batched GEMM tiles its columns by 128 or 144: channel counts without such a tiling (145..160, 305..320, 785..800, ...)
+            # stay on the direct kernels, which fall back through rg_igemm4_ok to the 64/80-column tiles
+            and _L().rg_gemm_batched_tile_n(int(cols)) >= 8)
 
 
 def _wino_fits(n, out_spatial, k, nout):
@@ -470,8 +492,8 @@ def _wino_weights(weight):
     L = _L()
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     wd = weight.detach()
-    U = torch.empty(64 * L.rg_wino_weights_rows(cout) * L.rg_wino_weights_red(cin), dtype=storage_dtype(), device=weight.device)
-    Ut = torch.empty(64 * L.rg_wino_weights_rows(cin) * L.rg_wino_weights_red(cout), dtype=storage_dtype(), device=weight.device)
+    U = _debug.empty(64 * L.rg_wino_weights_rows(cout) * L.rg_wino_weights_red(cin), storage_dtype(), weight.device)
+    Ut = _debug.empty(64 * L.rg_wino_weights_rows(cin) * L.rg_wino_weights_red(cout), storage_dtype(), weight.device)
     _lib.check(L.rg_wino_weights(C.c_void_p(wd.data_ptr()), int(is_cl_weight(wd)), cout, cin, C.c_void_p(U.data_ptr()),
                                  C.c_void_p(Ut.data_ptr()), _stream()), "rg_wino_weights")
     cache[wkey] = (U, Ut)
@@ -487,8 +509,8 @@ def _wino_conv(x, Wt, bias, act, slope, y, origin):
     tiles = [(int(o) + 1) // 2 for o in y.shape[2:]]
     nt = n_ * tiles[0] * tiles[1] * tiles[2]
     cs, ms = int(L.rg_wino_weights_red(k)), int(L.rg_wino_weights_red(nout))
-    V = torch.empty(64 * nt * cs, dtype=storage_dtype(), device=x.device)
-    M = torch.empty(64 * nt * ms, dtype=storage_dtype(), device=x.device)
+    V = _debug.empty(64 * nt * cs, storage_dtype(), x.device)
+    M = _debug.empty(64 * nt * ms, storage_dtype(), x.device)
     dx, dy = desc(x), desc(y)
     bptr = C.c_void_p(bias.data_ptr()) if bias is not None else None
 
@@ -510,14 +532,13 @@ def _wino_conv(x, Wt, bias, act, slope, y, origin):
 def _wgrad(g, x, p, shape, channels_last=False):
     """fp32 weight gradient of logical `shape` (a, b, KD, KH, KW); channels_last: in torch.channels_last_3d memory, which is
     the [a][tap][b] order the kernels accumulate in (no transpose pass; with one row split no reduction pass either)."""
-    dw = torch.empty(shape, dtype=torch.float32, device=g.device,
-                     memory_format=torch.channels_last_3d if channels_last else torch.contiguous_format)
+    dw = _debug.empty(shape, torch.float32, g.device, channels_last_3d=channels_last)
     ns = C.c_int32(0)
     dg, dx = desc(g), desc(x)
     nbytes = _L().rg_conv3d_wgrad_workspace_bytes(C.byref(dg), C.byref(dx), C.byref(p), C.byref(ns))
     if nbytes < 0:
         _lib.check(-1, "rg_conv3d_wgrad_workspace_bytes")
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g.device)
+    ws = _debug.empty(max(nbytes, 16), torch.uint8, g.device)
     _timed(_conv_flops(p, g.shape[0], x.shape[1], g.shape[1]),
            lambda: _lib.check(_L().rg_conv3d_wgrad2(C.byref(dg), C.byref(dx), C.c_void_p(dw.data_ptr()), C.byref(p),
                                                           2 if channels_last else 0, C.c_void_p(ws.data_ptr()), nbytes, _stream()),
@@ -558,10 +579,10 @@ def _act_bwd_bias(gy, y, act, slope, want_bias):
         return gy, None
     n, c, d, h, w = gy.shape
     g = cl_empty(n, c, d, h, w, gy.device) if act != "none" else None
-    db = torch.empty(c, dtype=torch.float32, device=gy.device) if want_bias else None
+    db = _debug.empty(c, torch.float32, gy.device) if want_bias else None
     dgy = desc(gy)
     nbytes = _L().rg_act_bwd_bias_workspace_bytes(C.byref(dgy)) if want_bias else 0
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=gy.device)
+    ws = _debug.empty(max(nbytes, 16), torch.uint8, gy.device)
     _lib.check(_L().rg_act_bwd_bias(C.byref(dgy), C.byref(desc(y)) if act != "none" else None,
                                           C.byref(desc(g)) if g is not None else None,
                                           C.c_void_p(db.data_ptr()) if want_bias else None, ACT[act], float(slope),
@@ -964,8 +985,8 @@ class _SubpixelWeights(Function):
         if w.dtype != torch.float32 or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3) or not is_dense(w):
             raise RuntimeError("raygun_amd: subpixel_weights expects a dense fp32 (O, C, 3, 3, 3) weight")
         o, c = w.shape[:2]
-        wf = torch.empty((o, cf, 3, 3, 3), dtype=torch.float32, device=w.device, memory_format=torch.channels_last_3d)
-        weff = torch.empty((8 * o, c - cf, 2, 2, 2), dtype=torch.float32, device=w.device, memory_format=torch.channels_last_3d)
+        wf = _debug.empty((o, cf, 3, 3, 3), torch.float32, w.device, channels_last_3d=True)
+        weff = _debug.empty((8 * o, c - cf, 2, 2, 2), torch.float32, w.device, channels_last_3d=True)
         _lib.check(_L().rg_subpixel_weights(C.byref(desc(w)), cf, C.c_void_p(wf.data_ptr()), C.c_void_p(weff.data_ptr()), _stream()),
                    "rg_subpixel_weights")
         ctx.cfg = (cf, tuple(w.shape), tuple(w.stride()))
@@ -1062,8 +1083,8 @@ class _InstanceNorm(Function):
         L = _L()
         dx = desc(x)
         nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        mr = torch.empty(n * c * 2, dtype=torch.float32, device=x.device)
+        ws = _debug.empty(nbytes, torch.uint8, x.device)
+        mr = _debug.empty(n * c * 2, torch.float32, x.device)
         _lib.check(L.rg_instnorm_stats(C.byref(dx), C.c_void_p(mr.data_ptr()), float(eps), C.c_void_p(ws.data_ptr()), nbytes,
                                        _stream()), "rg_instnorm_stats")
         y = cl_empty(n, c, d, h, w, x.device)
@@ -1085,7 +1106,7 @@ class _InstanceNorm(Function):
             L = _L()
             dx = desc(x)
             nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            ws = _debug.empty(nbytes, torch.uint8, x.device)
             gx = cl_empty(n, c, d, h, w, x.device)
             _lib.check(L.rg_instnorm_bwd(C.byref(dx), C.c_void_p(mr.data_ptr()), C.byref(desc(y)) if y is not None else None,
                                          C.byref(desc(gy)), C.byref(desc(gx)), ACT[act], float(slope),
@@ -1299,8 +1320,8 @@ class _Loss(Function):
         w = weight.detach().float().contiguous().view(-1) if weight is not None else None
         if t is not None and t.numel() != p.numel():
             raise RuntimeError(f"The size of tensor a ({tuple(pred.shape)}) must match the size of tensor b ({tuple(target.shape)})")
-        out = torch.empty(_LOSS_OUT, dtype=torch.float32, device=p.device)
-        grad = torch.empty_like(p)
+        out = _debug.empty(_LOSS_OUT, torch.float32, p.device)
+        grad = _debug.empty(p.shape, p.dtype, p.device)
         _lib.check(_L().rg_loss_fwd_bwd(kind, C.byref(desc(p)), C.byref(desc(t)) if t is not None else None,
                                               C.byref(desc(w)) if w is not None else None, float(const_target), 1.0,
                                               C.byref(desc(grad)), C.c_void_p(out.data_ptr()), _stream()), "rg_loss_fwd_bwd")

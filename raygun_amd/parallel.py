@@ -34,6 +34,56 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def launch_ranks(argv, n, timeout=None, rank0_stdout=None, env=None, poll_s=0.2, grace_s=10.0):
+    """Start `n` rank processes (torchrun-style environment, rendezvous on 127.0.0.1; backend nccl = RCCL unless the environment
+    says otherwise) from a parent that never touches the GPU, and SUPERVISE them: the children are polled; on the first non-zero
+    exit, or when `timeout` seconds have passed, the remaining ranks are terminated (SIGTERM, SIGKILL after `grace_s`) — a dead
+    rank otherwise leaves its siblings waiting in a collective until the watchdog fires, and the parent with them.  Rank 0 inherits
+    `rank0_stdout` (default: the parent's stdout), the other ranks' stdout goes to the parent's stderr.  Returns the first
+    non-zero exit code (124 on timeout, like timeout(1)), else 0."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    try:
+        err = sys.stderr.fileno()
+    except Exception:   # a captured / replaced sys.stderr (pytest): the process's own fd 2
+        err = 2
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=rank0_stdout if r == 0 else err))
+    t0, rc = time.monotonic(), 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                return 0
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                sys.stderr.write(f"[raygun_amd.launch_ranks] timeout after {timeout:.0f} s: terminating {sum(c is None for c in codes)} rank(s)\n")
+                rc = 124
+                break
+            time.sleep(poll_s)
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t1 = time.monotonic()
+        for p in live:
+            try:
+                p.wait(max(0.1, grace_s - (time.monotonic() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc if rc > 0 else 128 - rc if rc < 0 else 1   # a rank killed by signal k exits "negative k": report 128 + k
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -157,6 +207,68 @@ class GradSync:
                 n = g.numel()
                 _flat(g).reshape(-1).copy_(flat[off:off + n])
                 off += n
+
+
+# ---- small exchanges of the sharded non-training paths (slab mutex watershed) ---------------------------------------------------
+# RCCL ("nccl") moves device tensors; gloo — the CPU tests, and the one-GPU rehearsals where several ranks share a device, which
+# RCCL refuses — implements all_gather / send / recv for host tensors only, so there the payload is staged through the host.
+def _host_staged(group=None):
+    return dist.get_backend(group) != "nccl"
+
+
+def all_gather_ints(vals, group=None):
+    """[[rank 0's ints], [rank 1's ints], ...] — per-rank lists may differ in length."""
+    ws = dist.get_world_size(group)
+    dev = "cpu" if _host_staged(group) else torch.device("cuda", torch.cuda.current_device())
+    n = torch.tensor([len(vals)], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(ns, n, group=group)
+    mx = max(1, max(int(v.item()) for v in ns))
+    pad = torch.zeros(mx, dtype=torch.int64, device=dev)
+    if len(vals):
+        pad[:len(vals)] = torch.tensor([int(v) for v in vals], dtype=torch.int64)
+    bufs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad, group=group)
+    return [[int(v) for v in b[:int(k.item())].tolist()] for b, k in zip(bufs, ns)]
+
+
+def all_gather_cat(t, group=None):
+    """torch.cat of every rank's `t` along dim 0 (lengths may differ; trailing dims must agree), on t's device."""
+    ws = dist.get_world_size(group)
+    lens = [v[0] for v in all_gather_ints([t.shape[0]], group)]
+    mx = max(1, max(lens))
+    staged = _host_staged(group) and t.is_cuda
+    src = t.cpu() if staged else t
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+    pad[:t.shape[0]] = src
+    bufs = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad, group=group)
+    out = torch.cat([b[:k] for b, k in zip(bufs, lens)])
+    return out.to(t.device) if staged else out
+
+
+def neighbor_exchange(to_prev, to_next, group=None):
+    """Send `to_prev` to rank - 1 and `to_next` to rank + 1 (None at the ends of the chain); returns (from_prev, from_next),
+    tensors shaped like what was sent that way (None at the ends).  All ranks call it."""
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
+    staged = _host_staged(group)
+    dev = (to_prev if to_prev is not None else to_next).device if (to_prev is not None or to_next is not None) else None
+    h = lambda t: t.cpu().contiguous() if staged else t.contiguous()  # noqa: E731
+    ops_, from_prev, from_next = [], None, None
+    if rank > 0 and to_prev is not None:
+        sp = h(to_prev); from_prev = torch.empty_like(sp)
+        ops_ += [dist.P2POp(dist.isend, sp, dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group),
+                 dist.P2POp(dist.irecv, from_prev, dist.get_global_rank(group, rank - 1) if group is not None else rank - 1, group)]
+    if rank < ws - 1 and to_next is not None:
+        sn = h(to_next); from_next = torch.empty_like(sn)
+        ops_ += [dist.P2POp(dist.isend, sn, dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group),
+                 dist.P2POp(dist.irecv, from_next, dist.get_global_rank(group, rank + 1) if group is not None else rank + 1, group)]
+    for r in (dist.batch_isend_irecv(ops_) if ops_ else []):
+        r.wait()
+    if staged:
+        from_prev = from_prev.to(dev) if from_prev is not None else None
+        from_next = from_next.to(dev) if from_next is not None else None
+    return from_prev, from_next
 
 
 def broadcast_parameters(module, src=0):

@@ -62,6 +62,9 @@ def _to_destination(out, dtype, on_device=False):
     return out.cpu().numpy().astype(dtype)
 
 
+FALLBACK_BLOCKS = []   # block indices the f16 runner re-ran with bf16 storage (diagnostics; appended per call)
+
+
 @torch.no_grad()
 def predict_volume(model, source, input_shape=None, output_shape=None, read_size=None, crop=0, ndims=3,
                    scaleShift_input=None, out_dtypes=None, out_channels=None, rank=None, world=None, device=None,
@@ -78,7 +81,9 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
 
     `precision`: 16-bit storage type of the forward pass, "f16" (default for prediction: IEEE half, 11 significant bits —
     config U's affinities land within 1e-3 relative L2 of the fp32 reference; same kernel speed) or "bf16" (the
-    training type).  RAYGUN_AMD_PREDICT_PRECISION overrides the default."""
+    training type).  RAYGUN_AMD_PREDICT_PRECISION overrides the default.  Half's largest value is 65504: a block whose f16 run
+    produces a non-finite output (fp32 and bf16 would not overflow there) is predicted again with bf16 storage and logged
+    (`predict.FALLBACK_BLOCKS`); with bf16 storage a non-finite output raises FloatingPointError."""
     precision = precision or os.environ.get("RAYGUN_AMD_PREDICT_PRECISION", "f16")
     with ops.precision(precision):
         return _predict_volume(model, source, input_shape, output_shape, read_size, crop, ndims, scaleShift_input, out_dtypes,
@@ -117,66 +122,97 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         return torch.from_numpy(a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))).pin_memory()
 
     n_done = 0
-    drain = None
+    state = dict(drain=None, destinations=destinations)
     ahead = None
     if not resident and len(mine):
         from concurrent.futures import ThreadPoolExecutor
         reader = ThreadPoolExecutor(max_workers=1)
         ahead = reader.submit(fetch, mine[0])
-    try:
-        for k, bi in enumerate(mine):
-            wz, wy, wx = blocks[bi]
-            rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
+
+    def run_block(bi, host):
+        """Forward + crop + convert + hand-over of one block; returns a 0-d device bool: every output value finite."""
+        wz, wy, wx = blocks[bi]
+        rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
+        if resident:
+            blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
+        else:
+            blk = host.to(dev, non_blocking=True)[None, None]
+        if blk.dtype not in (torch.uint8,):
+            blk = blk.float()
+        x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
+        outs = model(x)
+        if not isinstance(outs, (tuple, list)):
+            outs = (outs,)
+        if state["destinations"] is None:
+            dd = []
+            for i, o in enumerate(outs):
+                c = o.shape[1]
+                dt = np.float32 if out_dtypes is None else out_dtypes[i]
+                shp = ((c,) if c > 1 else ()) + tuple(source.shape)
+                dd.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
+            state["destinations"] = dd
+        dests = state["destinations"]
+        out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in dests}
+        finite = None
+        for o, dest in zip(outs, dests):
+            o = o.detach().float()[0]
+            if crop and crop != 0 and input_shape is None:
+                o = o[..., crop:-crop, crop:-crop, crop:-crop]
+            if tuple(o.shape[-3:]) != tuple(write):
+                off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
+                o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
+            f = torch.isfinite(o).all()
+            finite = f if finite is None else finite & f
             if resident:
-                blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
-            else:
+                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
+            elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
+                dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
+            else:  # convert on the GPU, then let the drain thread download and scatter while the next block computes
+                if state["drain"] is None:
+                    state["drain"] = _Drain(dev)
+                state["drain"].put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
+                                   (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
+        return finite
+
+    try:
+        flags = []
+        for k, bi in enumerate(mine):
+            host = None
+            if not resident:
                 host = ahead.result()
                 ahead = reader.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
-                blk = host.to(dev, non_blocking=True)[None, None]
-            if blk.dtype not in (torch.uint8,):
-                blk = blk.float()
-            x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
-            outs = model(x)
-            if not isinstance(outs, (tuple, list)):
-                outs = (outs,)
-            if destinations is None:
-                destinations = []
-                for i, o in enumerate(outs):
-                    c = o.shape[1]
-                    dt = np.float32 if out_dtypes is None else out_dtypes[i]
-                    shp = ((c,) if c > 1 else ()) + tuple(source.shape)
-                    destinations.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
-            out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in destinations}
-            for o, dest in zip(outs, destinations):
-                o = o.detach().float()[0]
-                if crop and crop != 0 and input_shape is None:
-                    o = o[..., crop:-crop, crop:-crop, crop:-crop]
-                if tuple(o.shape[-3:]) != tuple(write):
-                    off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
-                    o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
-                if resident:
-                    dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
-                elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
-                    dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
-                else:  # convert on the GPU, then let the drain thread download and scatter while the next block computes
-                    if drain is None:
-                        drain = _Drain(dev)
-                    drain.put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
-                              (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
+            flags.append(run_block(bi, host))
             n_done += 1
+        # IEEE-half storage overflows at 65504 where fp32 (the reference) and bf16 stay finite, and integer destinations would
+        # clamp the inf / NaN silently: the per-block flags are read ONCE, after the last block (no per-block sync), and a block
+        # with a non-finite output is predicted again with bf16 storage — its destination region is simply written a second time
+        bad = [bi for bi, ok in zip(mine, torch.stack(flags).tolist()) if not ok] if flags else []
+        if bad:
+            if ops.storage_dtype() == torch.bfloat16:
+                raise FloatingPointError(f"raygun_amd.predict: non-finite network output in {len(bad)} block(s) with bf16 storage "
+                                         f"(first: block {bad[0]} at {blocks[bad[0]]})")
+            import logging
+            logging.getLogger("raygun_amd.predict").warning(
+                "non-finite output in %d of %d block(s) with f16 storage (half's range is 65504): re-running them with bf16 storage", len(bad), len(mine))
+            with ops.precision("bf16"):
+                again = [run_block(bi, None if resident else fetch(bi)) for bi in bad]
+            if not all(torch.stack(again).tolist()):
+                raise FloatingPointError("raygun_amd.predict: non-finite network output with bf16 storage as well")
+            FALLBACK_BLOCKS.extend(bad)
     except BaseException:  # a failing block must not leave the download / prefetch threads behind
-        if drain is not None:
+        if state["drain"] is not None:
             try:
-                drain.close()
+                state["drain"].close()
             except BaseException:
                 pass
         if not resident and len(mine):
             reader.shutdown(wait=False)
         raise
-    if drain is not None:
-        drain.close()
+    if state["drain"] is not None:
+        state["drain"].close()
     if not resident and len(mine):
         reader.shutdown()
+    destinations = state["destinations"]
     return destinations, n_done
 
 

@@ -125,6 +125,9 @@ def prepare_weights(affs, sep, mask_thresh, max_affinity_value, device=None):
     return w, m
 
 
+SINGLE_PASS_EDGE_IDS = 2 ** 32 - 2 ** 24   # one rg_mws_segment pass numbers its edges n_offsets * voxels < 2^32
+
+
 def _mws_params(shape, n_off, n_attr, strides, invert, bias, origin):
     p = rg_mws_params()
     for i in range(3):
@@ -155,11 +158,16 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
          cross edge, can never merge and are left out — exact, not an approximation of the definition;
       4. relabel: 1 + rank of the cluster's first voxel in global raster order, 0 = masked out (rg_mws_relabel).
 
-    One process, several slabs: pass the whole (n_offsets, Z, Y, X) volume and `n_slabs` / `bounds`.  One slab per rank
-    (torch.distributed initialised, backend nccl = RCCL): pass THIS rank's slab, `z0` = its first global plane and
-    `global_shape`; slabs are ordered by rank.  Step 2 is then a neighbour send/recv, step 3 runs replicated on every rank
-    from an all-gather of the (small) edge records.  Returns this process's labels (uint64 ndarray, or int64 tensor)."""
+    One process, several slabs: pass the whole (n_offsets, Z, Y, X) volume and `n_slabs` / `bounds`.  Several ranks
+    (torch.distributed initialised; backend nccl = RCCL, or gloo with the payloads staged through the host): pass THIS rank's
+    part of the volume, `z0` = its first global plane and `global_shape`; parts are ordered by rank.  A rank's part is itself cut
+    into `n_slabs` sub-slabs (default: as many as the single-pass limit n_offsets * voxels < 2^32 asks for — config 5's
+    2048^3 / 8 ranks needs 6 per rank), or at the LOCAL plane indices `bounds`; the global decomposition is the concatenation
+    of all ranks' sub-slabs, and the result equals the one-process result with those bounds.  Step 2 is then a neighbour
+    send/recv at rank boundaries, step 3 runs replicated on every rank from an all-gather of the (small) edge records.
+    Returns this process's labels (uint64 ndarray, or int64 tensor)."""
     import torch.distributed as dist
+    from . import parallel
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("raygun_amd.segment_slabs runs on the MI355X only (no CPU fallback)")
@@ -175,34 +183,37 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     H = max(1, int(np.abs(off_np[:, 0]).max()))
-    if distributed:
-        Zg = int(global_shape[0])
-        mine = [(int(z0), Zl)]
-    else:
-        Zg = Zl
-        if bounds is None:
-            bounds = slab_bounds(Zl, n_slabs or 1, H)
-        mine = [(int(a), int(b - a)) for a, b in zip(bounds[:-1], bounds[1:])]
-    if any(t < H for _, t in mine) and (len(mine) > 1 or distributed):
+    zbase = int(z0) if distributed else 0
+    Zg = int(global_shape[0]) if distributed else Zl
+    if bounds is None:
+        auto = -(-(K * Zl * Y * X) // SINGLE_PASS_EDGE_IDS)          # sub-slabs the single-pass limit asks for
+        bounds = slab_bounds(Zl, max(int(n_slabs or 1), auto), H)
+    mine = [(zbase + int(a), int(b - a)) for a, b in zip(bounds[:-1], bounds[1:])]
+    bad = any(t < H for _, t in mine) and (len(mine) > 1 or distributed)
+    if distributed:   # every rank must reach the collectives below or none: agree on validity first
+        flags = parallel.all_gather_ints([int(bad), len(mine)], group)
+        bad = any(f[0] for f in flags)
+        nsub = [f[1] for f in flags]
+    if bad:
         raise ValueError(f"slabs must be at least max|dz| = {H} planes thick")
     L = _lib.lib()
     st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
     # ---- 1. first level
     labs, counts = [], []
     for zs, t in mine:
-        zl = zs - (int(z0) if distributed else 0)
+        zl = zs - zbase
         lab = compute_mws_segmentation(w[:, zl:zl + t], off_np, n_attr, strides, mask=None if m is None else m[zl:zl + t],
                                        invert_repulsive_weights=invert_repulsive_weights, bias_cut=bias_cut, device=dev,
                                        as_tensor=True, origin=(zs, 0, 0))
         if int(lab.view(-1)[0].item()) == -1:
             raise RuntimeError("raygun_amd.segment_slabs: the device pass made no progress (internal error)")
         labs.append(lab); counts.append(int(lab.max().item()))
-    if distributed:
-        allc = torch.zeros(world, dtype=torch.int64, device=dev)
-        allc[rank] = counts[0]
-        dist.all_reduce(allc, group=group)
-        all_counts = [int(v) for v in allc.tolist()]
-        my_ids = [rank]
+    if distributed:   # global slab list = every rank's sub-slabs, in rank order
+        per_rank = parallel.all_gather_ints(counts, group)
+        assert [len(c) for c in per_rank] == nsub
+        all_counts = [c for cs in per_rank for c in cs]
+        first = sum(nsub[:rank])
+        my_ids = list(range(first, first + len(mine)))
     else:
         all_counts, my_ids = counts, list(range(len(mine)))
     S = len(all_counts)
@@ -215,19 +226,14 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
         return torch.where(lab > 0, lab + int(bases[sid]), lab)
     top = {sid: glob(lab[:H], sid).contiguous() for sid, lab in zip(my_ids, labs)}      # first H planes
     bot = {sid: glob(lab[-H:], sid).contiguous() for sid, lab in zip(my_ids, labs)}     # last H planes
-    if distributed:
-        below = torch.zeros_like(top[rank]); above = torch.zeros_like(top[rank])
-        ops_ = []
-        if rank > 0:
-            ops_ += [dist.P2POp(dist.isend, top[rank], rank - 1, group), dist.P2POp(dist.irecv, below, rank - 1, group)]
-        if rank < world - 1:
-            ops_ += [dist.P2POp(dist.isend, bot[rank], rank + 1, group), dist.P2POp(dist.irecv, above, rank + 1, group)]
-        for r in dist.batch_isend_irecv(ops_) if ops_ else []:
-            r.wait()
-        nb_above = {rank: above}; nb_below = {rank: below}
-    else:
-        nb_above = {sid: top[sid + 1] for sid in my_ids if sid + 1 < S}
-        nb_below = {sid: bot[sid - 1] for sid in my_ids if sid > 0}
+    nb_above = {sid: top[sid + 1] for sid in my_ids if sid + 1 in top}
+    nb_below = {sid: bot[sid - 1] for sid in my_ids if sid - 1 in bot}
+    if distributed:   # the zones either side of a RANK boundary travel once, neighbour to neighbour
+        below, above = parallel.neighbor_exchange(top[my_ids[0]] if rank > 0 else None, bot[my_ids[-1]] if rank < world - 1 else None, group)
+        if below is not None:
+            nb_below[my_ids[0]] = below
+        if above is not None:
+            nb_above[my_ids[-1]] = above
     # ---- 3a. this process's edge records
     per_dir = {d: int(sum(abs(int(dz)) for dz in off_np[:, 0] if dz * d > 0)) * Y * X for d in (1, -1)}
     rec = dict(wkey=[], gid=[], gu=[], gv=[], attr=[])
@@ -235,7 +241,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     zone_ids = []
     Ng = Zg * Y * X
     for sid, lab, (zs, t) in zip(my_ids, labs, mine):
-        zl = zs - (int(z0) if distributed else 0)
+        zl = zs - zbase
         p = _mws_params((t, Y, X), K, n_attr, strides, invert_repulsive_weights, bias_cut, (zs, 0, 0))
         wsl = w[:, zl:zl + t].contiguous()
         for d, nz in ((1, nb_above.get(sid)), (-1, nb_below.get(sid))):
@@ -279,17 +285,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     mutp = torch.cat(mut) if mut else torch.zeros((0, 2), dtype=torch.int64, device=dev)
     nodes = torch.cat(zone_ids) if zone_ids else torch.zeros(0, dtype=torch.int64, device=dev)
     if distributed:  # replicate the (small) second-level input on every rank
-        def gather(t):
-            n = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
-            ns = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(ns, n, group=group)
-            mx = max(int(v.item()) for v in ns)
-            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-            pad[:t.shape[0]] = t
-            bufs = [torch.zeros_like(pad) for _ in range(world)]
-            dist.all_gather(bufs, pad, group=group)
-            return torch.cat([b[:int(k.item())] for b, k in zip(bufs, ns)])
-        wkey, gid, gu, gv, attr, mutp, nodes = [gather(t) for t in (wkey, gid, gu, gv, attr, mutp, nodes)]
+        wkey, gid, gu, gv, attr, mutp, nodes = [parallel.all_gather_cat(t, group) for t in (wkey, gid, gu, gv, attr, mutp, nodes)]
     # ---- 3b. second level on compact node indices (sorted global ids: the smallest index is the smallest id)
     nodes = torch.unique(nodes)
     n_nodes = int(nodes.numel())
@@ -356,7 +352,7 @@ def mutex_segment(config_path, affs=None):
         affs = np.asarray(affs, dtype=np.float32)
     weights, mask = prepare_weights(affs, seg_config["sep"], seg_config["mask_thresh"], seg_config["max_affinity_value"])
     n_vox = int(np.prod(weights.shape[1:]))
-    n_slabs = seg_config.get("n_slabs") or -(-(n_vox * weights.shape[0]) // (2 ** 32 - 2 ** 24))   # one pass holds n_offsets * voxels < 2^32 edge ids
+    n_slabs = seg_config.get("n_slabs") or -(-(n_vox * weights.shape[0]) // SINGLE_PASS_EDGE_IDS)   # one pass holds n_offsets * voxels < 2^32 edge ids
     if n_slabs > 1:   # beyond one pass (or on request): Z-slabs + one exchange step; the result is defined by that decomposition
         seg = segment_slabs(weights, neighborhood, seg_config["sep"], strides=[10, 10, 10], mask=mask, n_slabs=n_slabs)
     else:

@@ -7,7 +7,6 @@ Data parallelism has no reference counterpart (single GPU): when th
 which starts N such processes itself — every rank builds the same system, rank 0's weights are broadcast, and the gradients
 are averaged over RCCL before each optimiser step (raygun_amd.parallel.GradSync)."""
 import os
-import subprocess
 import sys
 
 from .load_system import load_system
@@ -31,20 +30,11 @@ def train(config_path=None, batches=None):
     return out
 
 
-def launch(n_gpus, argv):
-    """Start one training process per GPU (torchrun-style environment, rendezvous on 127.0.0.1) from a parent that never
-    touches the GPU; returns the first non-zero exit code."""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    for r in range(n_gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, "-m", "raygun_amd.train"] + list(argv), env=env))
-    rc = 0
-    for p in procs:
-        rc = rc or p.wait()
-    return rc
+def launch(n_gpus, argv, timeout=None):
+    """Start one training process per GPU from a parent that never touches the GPU (parallel.launch_ranks: the ranks are
+    supervised — the first failing rank, or the timeout, ends them all); returns the first non-zero exit code."""
+    from .parallel import launch_ranks
+    return launch_ranks([sys.executable, "-m", "raygun_amd.train"] + list(argv), n_gpus, timeout=timeout)
 
 
 def main(argv=None):

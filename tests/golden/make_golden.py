@@ -239,7 +239,14 @@ def _cyc_cfg(nd, gk, dk, loss_type, lr=5e-4, d_lr=None):
                 g_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=lr if d_lr is None else d_lr))
 
 
-def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_lr=5e-4, d_lr=5e-4):
+def _grad_sums(nets):
+    """{net: {param: [sum, sum|.|]}} of the gradients the step left in .grad (G nets: the generator phase's, D nets: the
+    discriminator phase's — LinkCycleLoss.py:121-135,61-85 zero them per phase, nothing clears them afterwards)."""
+    return {k: {n: [float(p.grad.double().sum()), float(p.grad.double().abs().sum())] for n, p in net.named_parameters() if p.grad is not None}
+            for k, net in nets.items()}
+
+
+def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_lr=5e-4, d_lr=5e-4, sampled=False):
     cfg = _cyc_cfg(nd, dict(gk), dict(dk), loss_type, g_lr, d_lr)
     if loss_kwargs:
         cfg["loss_kwargs"] = loss_kwargs
@@ -251,7 +258,7 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_
     nets_o = dict(G1=model.netG1, G2=model.netG2, D1=loss.netD1, D2=loss.netD2)
     for i, k in enumerate(nets_r):
         same_weights(nets_r[k], nets_o[k], 80 + i)
-    recs = []
+    recs, samp_recs = [], []
     for it in range(iters):
         A = T(synth.uniform(shape, 90 + 2 * it)); B = T(synth.uniform(shape, 91 + 2 * it))
         rs.optimizer.zero_grad()
@@ -265,6 +272,17 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_
             close(rd[k], od[k], 2e-5, f"{tag}.it{it}.{k}")
         close(fB.detach().numpy(), outs[0].detach().numpy(), 2e-5, f"{tag}.it{it}.fake_B")
         recs.append(rd)
+        if sampled:   # full-width configurations: sampled outputs + sum / sum|.| of every gradient tensor, per iteration
+            gr, go = _grad_sums(nets_r), _grad_sums(nets_o)
+            for k in gr:
+                for n in gr[k]:
+                    close(gr[k][n][1], go[k][n][1], 1e-4, f"{tag}.it{it}.gradabs.{k}.{n}")
+            flat = {"fake_B": fB, "cycled_B": cB, "fake_A": fA, "cycled_A": cA}
+            for nm, (t_ref, t_ora) in {nm: (flat[nm], outs[i]) for i, nm in enumerate(["fake_B", "cycled_B", "fake_A", "cycled_A"])}.items():
+                close(t_ref.detach().numpy(), t_ora.detach().numpy(), 2e-5, f"{tag}.it{it}.{nm}")
+            idx = (np.arange(4096, dtype=np.int64) * 2654435761) % fB.numel()
+            samp_recs.append(dict(grad_sums=gr, idx=idx, **{nm: t.detach().reshape(-1)[idx].numpy() for nm, t in flat.items()},
+                                  **{nm + "_sum": [float(t.double().sum()), float(t.double().abs().sum())] for nm, t in flat.items()}))
     wsum = {}
     for k in nets_r:
         for n, p in nets_r[k].named_parameters():
@@ -275,7 +293,13 @@ def fx_cyclegan(tag, nd, shape, gk, dk, loss_type, loss_kwargs=None, iters=2, g_
     from raygun.torch.networks.utils import get_running_norm_stats
     rm, rv = get_running_norm_stats(rs.netG1)
     extra = {} if rm is None else dict(running_mean_G1=rm.numpy(), running_var_G1=rv.numpy())
-    save(tag, loss_dicts=json.dumps(recs), weight_sums=json.dumps(wsum), fake_B=fB.detach().numpy(), **extra,
+    if sampled:
+        extra["grad_sums"] = json.dumps([r["grad_sums"] for r in samp_recs])
+        extra["out_sums"] = json.dumps([{k: v for k, v in r.items() if k.endswith("_sum")} for r in samp_recs])
+        extra["sample_idx"] = samp_recs[0]["idx"]
+        for nm in ("fake_B", "cycled_B", "fake_A", "cycled_A"):
+            extra["sample_" + nm] = np.stack([r[nm] for r in samp_recs])
+    save(tag, loss_dicts=json.dumps(recs), weight_sums=json.dumps(wsum), **({} if sampled else dict(fake_B=fB.detach().numpy())), **extra,
          meta=json.dumps(dict(shape=list(shape), loss_type=loss_type, lr=g_lr, d_lr=d_lr, betas=[0.5, 0.999], iters=iters,
                               gk={k: str(v) for k, v in gk.items()}, dk={k: str(v) for k, v in dk.items()},
                               state_keys_model=list(rs.model.state_dict().keys()))))
@@ -393,7 +417,19 @@ def fx_residual_unet():
         save(name, **arrs)
 
 
+def fx_cyclegan_ngf64():
+    """BASELINE config 2 at its REAL width (ResNet ngf 64 / 6 blocks / 2 down / InstanceNorm3d / "same" + PatchD ngf 64 /
+    3 layers / kw 4, link loss, lsgan, lambda cycled 10) on 64^3 volumes (128^3 does not fit this container's 64 GB next to the
+    oracle's copy): 2 iterations — loss_dict, 4096 sampled values + sums of all four generator outputs, sum / sum|.| of every
+    gradient tensor of G1, G2, D1, D2.  The ngf-8 fixtures above never reach the 256-channel kernels, the split-K PatchGAN layers
+    or the composed 64 -> 64 7^3 tail."""
+    g3 = dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same")
+    d3 = dict(input_nc=1, ngf=64, n_layers=3, kw=4)
+    fx_cyclegan("cyclegan_step_link_3d64_ngf64", 3, (1, 1, 64, 64, 64), g3, d3, "link", iters=2, g_lr=1e-4, d_lr=1e-4, sampled=True)
+
+
 FIXTURES = {
+    "cyclegan_ngf64": fx_cyclegan_ngf64,
     "residual_unet": fx_residual_unet,
     "convpass": fx_convpass, "maxdown": fx_maxdown, "upsample": fx_upsample, "unet_small": fx_unet_small,
     "resnet": fx_resnet, "smooth": fx_smooth, "instnorm": fx_instnorm, "misc": fx_misc, "structure": fx_structure,

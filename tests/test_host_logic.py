@@ -14,6 +14,13 @@ def test_winograd_gating_is_per_pass():
     assert not ok(torch.empty(432, 2592, 3, 3, 3, device="meta"), backward=True) and ok(torch.empty(432, 2592, 3, 3, 3, device="meta"))
     assert not ok(w_sq, stride=(2, 2, 2)) and not ok(w_sq, padding=(1, 1, 1)) and not ok(w_sq, dw=True)
     assert not ok(torch.empty(2592, 2592, 2, 2, 2, device="meta")) and not ok(torch.empty(2592, 64, 3, 3, 3, device="meta"), backward=True)
+    # column counts the batched GEMM cannot tile by 128 / 144 (rg_gemm_batched refuses them) stay on the direct kernels
+    assert not ok(torch.empty(160, 1024, 3, 3, 3, device="meta")) and not ok(torch.empty(800, 4000, 3, 3, 3, device="meta"))
+    assert not ok(torch.empty(4000, 800, 3, 3, 3, device="meta"), backward=True)      # backward-data of 800 -> 4000: 800 columns
+    assert ok(torch.empty(144, 1024, 3, 3, 3, device="meta")) and ok(torch.empty(1024, 1152, 3, 3, 3, device="meta"), backward=True)
+    from raygun_amd import _lib
+    L = _lib.lib()
+    assert [L.rg_gemm_batched_tile_n(n) for n in (128, 144, 150, 160, 256, 288, 310, 800, 2592, 3456)] == [8, 9, 0, 0, 8, 9, 0, 0, 9, 9]
     os.environ["RAYGUN_AMD_WINOGRAD"] = "0"
     try:
         assert not ok(w_sq)

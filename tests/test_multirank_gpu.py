@@ -1,0 +1,267 @@
+"""Every multi-rank code path, executed on ONE GPU: N rank processes share cuda:0 and talk over gloo (RCCL refuses ranks that
+share a device; raygun_amd.parallel stages gloo's host-only collectives through the host).  Same code as the 8-GPU runs except for
+the backend string — tests/test_parallel_gpu.py keeps the RCCL variant for boxes with >= 2 GPUs.
+
+  * config 4 (DDP): DP(2) x 3 steps == one process on the concatenated batch, for the U-Net affinity system (GradSync.attach:
+    all-reduces started from backward hooks) and for the Link CycleGAN with raygun_amd networks + FusedAdam through `grad_sync`;
+  * config 5 (sharded mutex watershed): segment_slabs(..., z0, global_shape) on 2 and 3 ranks, and on 2 ranks x 2 sub-slabs,
+    bit-exact against oracle.mws.slab_mws with the identical global decomposition; an invalid (too thin) part raises on EVERY rank;
+  * config 5 (sharded block-wise predict): predict_zarr(world = 2) writes the same container as world = 1.
+At most 3 child processes (+ the pytest process) hold the GPU at once."""
+import functools
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from raygun_amd import synth
+
+pytestmark = pytest.mark.gpu
+NB8 = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [3, 0, 0], [0, 3, 0], [0, 0, 3], [2, 2, 0], [0, 2, -2]], np.int32)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _entry(fn, rank, world, port, q, args, backend):
+    local = rank if backend == "nccl" else 0       # gloo: all ranks on cuda:0; nccl (= RCCL): one device per rank
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        from raygun_amd import parallel
+        parallel.init_from_env(backend=backend)
+        torch.cuda.set_device(local)
+        q.put((rank, "ok", fn(rank, world, *args)))
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001  (reported to the parent, which fails the test)
+        import traceback
+        q.put((rank, "error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+        raise
+
+
+def run_ranks(fn, world, *args, timeout=600, backend="gloo"):
+    """Run fn(rank, world, *args) in `world` spawned processes sharing cuda:0 (gloo) or on one device each (nccl); returns the
+    results ordered by rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=timeout) for _ in procs), key=lambda r: r[0])
+        bad = [r for r in res if r[1] != "ok"]
+        assert not bad, "\n".join(f"rank {r[0]}: {r[2]}" for r in bad)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    return [r[2] for r in res]
+
+
+# ---------------------------------------------------------------------------------------------------- config 4: DP training
+def _mtlsd(dev):
+    from raygun_amd.torch.models import MTLSDModel
+    kw = {"input_nc": 1, "ngf": 4, "fmap_inc_factor": 2, "downsample_factors": [(2, 2, 2)], "constant_upsample": True}
+    m = MTLSDModel(unet_kwargs=kw, num_affs=3)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 5))
+    return m.to(dev)
+
+
+def _mtlsd_steps(m, raw, k, sync):
+    from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
+    from raygun_amd.torch.optimizers import FusedAdam
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    lf = WeightedMSELoss_MTLSD()
+    if sync is not None:
+        sync.attach(m.parameters())
+    for it in range(k):
+        opt.zero_grad(set_to_none=True)
+        affs, lsds = m(raw)
+        ga = torch.from_numpy(synth.uniform(tuple(affs.shape[1:]), 60, 0, 1)).to(raw.device).expand_as(affs)
+        gl = torch.from_numpy(synth.uniform(tuple(lsds.shape[1:]), 61, 0, 1)).to(raw.device).expand_as(lsds)
+        lf(lsds, gl, torch.ones_like(lsds), affs, ga, torch.ones_like(affs)).backward()
+        if sync is not None:
+            sync(list(m.parameters()))
+        opt.step()
+    return [p.detach().float().cpu() for p in m.parameters()]
+
+
+def _dp_unet(rank, world):
+    from raygun_amd import parallel
+    dev = torch.device("cuda", torch.cuda.current_device())
+    raw = torch.from_numpy(synth.uniform((world, 1, 36, 36, 36), 9)).to(dev)
+    sync = parallel.GradSync(small_bytes=2048)        # the small model's conv weights count as "large": hooks start them during backward
+    got = _mtlsd_steps(_mtlsd(dev), raw[rank:rank + 1], 3, sync)
+    ref = _mtlsd_steps(_mtlsd(dev), raw, 3, None)
+    err = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(got, ref))
+    return err, [float(p.double().sum()) for p in got], sync.stats
+
+
+def test_dp2_shared_gpu_unet_equals_big_batch():
+    res = run_ranks(_dp_unet, 2)
+    assert res[0][1] == res[1][1]                    # bitwise identical weights on both ranks
+    assert max(r[0] for r in res) <= 2e-2, res       # vs big batch: bf16 activations, batch-2 kernels vs two batch-1 runs
+    assert res[0][2]["large"] > 0 and res[0][2]["buckets"] >= 1, res[0][2]
+
+
+def _cyclegan(dev, grad_sync):
+    from raygun_amd.torch.systems import CycleGAN
+    IN = functools.partial(torch.nn.InstanceNorm3d)
+    cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
+               gnet_kwargs=dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN, padding_type="same"),
+               dnet_kwargs=dict(input_nc=1, ngf=8, n_layers=3, kw=4), loss_type="link", loss_kwargs={},
+               g_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), random_seed=None)
+    s = CycleGAN(cfg)
+    s.setup_networks()
+    for i, k in enumerate(["netG1", "netG2", "netD1", "netD2"]):
+        net = getattr(s, k)
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i))
+        net.to(dev)
+    s.setup_model()
+    s.setup_optimization(grad_sync=grad_sync)
+    return s
+
+
+def _cyclegan_steps(s, A, B, k):
+    for it in range(k):
+        s.optimizer.zero_grad()
+        fB, cB, fA, cA = s.model(real_A=A, real_B=B)
+        s.loss(A, fA, cA, B, fB, cB).backward()
+        s.optimizer.step()
+    return [p.detach().float().cpu() for n in (s.netG1, s.netG2, s.netD1, s.netD2) for p in n.parameters()]
+
+
+def _dp_cyclegan(rank, world):
+    import contextlib
+    import sys
+    from raygun_amd import parallel
+    from raygun_amd.torch.optimizers import FusedAdam
+    dev = torch.device("cuda", torch.cuda.current_device())
+    A = torch.from_numpy(synth.uniform((world, 1, 32, 32, 32), 90)).to(dev)
+    B = torch.from_numpy(synth.uniform((world, 1, 32, 32, 32), 91)).to(dev)
+    calls = []
+    sync = parallel.GradSync()
+
+    def counted(params):
+        calls.append(len(params)); sync(params)
+    with contextlib.redirect_stdout(sys.stderr):
+        s = _cyclegan(dev, counted)
+        r = _cyclegan(dev, None)
+    assert isinstance(s.optimizer_G, FusedAdam) and isinstance(s.optimizer_D, FusedAdam), "FusedAdam not in use"
+    init = [p.detach().float().cpu().clone() for n in (r.netG1, r.netG2, r.netD1, r.netD2) for p in n.parameters()]
+    got = _cyclegan_steps(s, A[rank:rank + 1], B[rank:rank + 1], 2)
+    ref = _cyclegan_steps(r, A, B, 2)
+    # Adam moves every element by ~lr per step whatever the gradient's size, so the comparison is in units of the update: the DP
+    # run's total update against the big-batch run's (bf16 gradients differ in the last bits; an element whose gradient is ~0
+    # may step the other way)
+    num = sum(float(((a - b) ** 2).sum()) for a, b in zip(got, ref))
+    den = sum(float(((b - i) ** 2).sum()) for b, i in zip(ref, init))
+    far = sum(int(((a - b).abs() > 5e-4).sum()) for a, b in zip(got, ref)) / sum(a.numel() for a in got)
+    return (num / den) ** 0.5, [float(p.double().sum()) for p in got], calls, far
+
+
+def test_dp2_shared_gpu_link_cyclegan_equals_big_batch():
+    """Link CycleGAN (raygun_amd generators / discriminators, FusedAdam) data-parallel over 2 ranks through the losses'
+    `grad_sync` hook (once per optimiser and iteration: G1 u G2, then D) == one process on the concatenated batch."""
+    res = run_ranks(_dp_cyclegan, 2)
+    assert res[0][1] == res[1][1]
+    assert len(res[0][2]) == 2 * 2, res[0][2]
+    # relative L2 of (DP weights - big-batch weights) against the big-batch UPDATE over the 2 steps, and the fraction of elements
+    # that ended more than one lr apart
+    assert max(r[0] for r in res) <= 0.15 and max(r[3] for r in res) <= 0.02, [(r[0], r[3]) for r in res]
+
+
+# ------------------------------------------------------------------------------------------- config 5: sharded mutex watershed
+def _blobs(shape, seed):
+    z, y, x = np.meshgrid(*[np.arange(s, dtype=np.float32) for s in shape], indexing="ij")
+    f = np.sin(z / 5.1 + seed) * np.sin(y / 6.3) * np.sin(x / 4.7 + 1.0)
+    return (np.abs(f) > 0.2).astype(np.float32) * 0.8 + 0.1
+
+
+def _slab_case(shape, seed, use_mask):
+    w = (0.7 * _blobs(shape, 2)[None] + 0.3 * synth.uniform((8,) + shape, seed, 0, 1)).astype(np.float32)
+    mask = (synth.uniform(shape, seed + 1, 0, 1) > 0.2) if use_mask else None
+    return w, mask
+
+
+def _seg_rank(rank, world, shape, parts, local_bounds, strides, use_mask):
+    from raygun_amd.segment import segment_slabs
+    w, mask = _slab_case(tuple(shape), 11, use_mask)
+    a, b = parts[rank], parts[rank + 1]
+    lab = segment_slabs(w[:, a:b], NB8, 3, strides, mask=None if mask is None else mask[a:b], z0=a, global_shape=shape,
+                        bounds=None if local_bounds is None else local_bounds[rank])
+    return lab
+
+
+@pytest.mark.parametrize("world,shape,parts,local_bounds,strides,use_mask", [
+    (2, (48, 40, 44), [0, 24, 48], None, (2, 2, 2), True),
+    (3, (60, 36, 40), [0, 17, 41, 60], None, (1, 1, 1), False),
+    (2, (64, 40, 40), [0, 30, 64], [[0, 14, 30], [0, 16, 34]], (4, 4, 4), True),     # 2 ranks x 2 sub-slabs each
+])
+def test_segment_slabs_across_ranks_bit_exact(world, shape, parts, local_bounds, strides, use_mask):
+    from oracle import mws as O
+    labs = run_ranks(_seg_rank, world, shape, parts, local_bounds, strides, use_mask)
+    got = np.concatenate(labs, 0)
+    if local_bounds is None:
+        gb = parts
+    else:
+        gb = sorted({parts[r] + b for r in range(world) for b in local_bounds[r]})
+    w, mask = _slab_case(tuple(shape), 11, use_mask)
+    ref = O.slab_mws(w, NB8, 3, strides, mask, gb)
+    assert got.dtype == np.uint64 and got.shape == ref.shape
+    assert (got == ref).all(), f"{int((got != ref).sum())} of {ref.size} labels differ"
+    assert got.max() > 1
+
+
+def _seg_thin(rank, world):
+    from raygun_amd.segment import segment_slabs
+    w, _ = _slab_case((20, 16, 16), 3, False)
+    parts = [0, 2, 20]          # rank 0's part is thinner than max|dz| = 3
+    try:
+        segment_slabs(w[:, parts[rank]:parts[rank + 1]], NB8, 3, (1, 1, 1), z0=parts[rank], global_shape=(20, 16, 16))
+    except ValueError as e:
+        return str(e)
+    return "no error"
+
+
+def test_segment_slabs_invalid_part_raises_on_every_rank():
+    """A part thinner than max|dz| is an error on ALL ranks (agreed on before the first collective) — not a hang of the others."""
+    res = run_ranks(_seg_thin, 2, timeout=120)
+    assert all("planes thick" in r for r in res), res
+
+
+# ------------------------------------------------------------------------------------------- config 5: sharded block-wise predict
+def _predict_rank(rank, world, path):
+    from raygun_amd import predict as P
+    from raygun_amd.torch.networks import UNet
+    dev = torch.device("cuda", 0)
+    net = UNet(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True, output_nc=3)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict(), 3))
+    net = net.to(dev)
+    P.predict_zarr(lambda t: torch.sigmoid(net(t)), path, "volumes/raw", output_ds=[f"volumes/pred_w{world}"],
+                   out_specs={f"volumes/pred_w{world}": {"dtype": np.uint8}}, input_shape=[36] * 3, output_shape=[20] * 3, out_channels=[3],
+                   rank=rank, world=world)
+    return True
+
+
+def test_predict_zarr_two_ranks_equals_one(tmp_path):
+    from raygun_amd import zarrio
+    vol = (synth.uniform((76, 60, 60), 4, 0, 1) * 255).astype(np.uint8)
+    path = str(tmp_path / "vol.zarr")
+    raw = zarrio.prepare_ds(path, "volumes/raw", vol.shape, (4, 4, 4), np.uint8, write_size=(16, 16, 16), offset=(0, 0, 0), compressor=None)
+    raw[...] = vol
+    run_ranks(_predict_rank, 2, path)
+    run_ranks(_predict_rank, 1, path)
+    a = zarrio.open_ds(path, "volumes/pred_w2")[...]
+    b = zarrio.open_ds(path, "volumes/pred_w1")[...]
+    assert a.shape == (3, 76, 60, 60) and a.any() and np.array_equal(a, b)

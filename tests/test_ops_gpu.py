@@ -423,11 +423,15 @@ def test_wide_transposed_conv_subpixel_path():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cout", [144, 128])
-def test_igemm4_192_row_tiles(cout, monkeypatch):
+def test_igemm4_192_row_tiles(cout):
     """The 192-row tile (FM = 3) of igemm4 is only picked for large grids; force it (RG_FM=3) on a small problem: forward and
     backward-data against torch fp32 on the CPU."""
     from raygun_amd import ops
-    monkeypatch.setenv("RG_FM", "3")
+    with ops.option("RG_FM", 3):
+        _igemm4_192_row_tiles(cout, ops)
+
+
+def _igemm4_192_row_tiles(cout, ops):
     dev = torch.device("cuda")
     torch.manual_seed(5)
     x0 = bf(torch.randn(1, 64, 9, 10, 11)); w = bf(torch.randn(cout, 64, 3, 3, 3) * 0.05); b = torch.randn(cout)
@@ -531,7 +535,7 @@ def test_instance_norm_running_stats_matches_torch(nd):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,sp,pad,act", [(12, 12, (36, 40, 44), 0, "relu"), (16, 9, (33, 35, 70), 1, "sigmoid"), (10, 16, (40, 37, 41), 0, "none")])
-def test_halo16_thin_conv_forward_and_backward_data(cin, cout, sp, pad, act, monkeypatch):
+def test_halo16_thin_conv_forward_and_backward_data(cin, cout, sp, pad, act):
     """conv5.hip halo16_kernel (input halo tile in LDS, weights in registers: the 12 -> 12 U-Net levels) — forward, fused bias /
     activation, zero padding, ragged tile edges and the backward-data pass (flipped taps) against torch fp32 on the CPU, and
     identical to the persistent thin kernel it replaces (RG_NO_HALO=1)."""
@@ -545,13 +549,12 @@ def test_halo16_thin_conv_forward_and_backward_data(cin, cout, sp, pad, act, mon
     (gxr,) = torch.autograd.grad(yr, xr, go)
     outs = {}
     for flag in ("", "1"):
-        if flag:
-            monkeypatch.setenv("RG_NO_HALO", "1")
-        xd = x0.clone().to(dev).requires_grad_()
-        y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, pad, act)
-        name = _lib.lib().rg_last_kernel_name().decode()
-        assert ("halo16" in name) == (flag == ""), name
-        (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+        with ops.option("RG_NO_HALO", 1 if flag else 0):
+            xd = x0.clone().to(dev).requires_grad_()
+            y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, pad, act)
+            name = _lib.lib().rg_last_kernel_name().decode()
+            assert ("halo16" in name) == (flag == ""), name
+            (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
         assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL
         assert float(y[:, cout:].abs().max()) == 0 if y.shape[1] > cout else True
         outs[flag] = (y.float().cpu(), gx.float().cpu())

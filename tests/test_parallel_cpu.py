@@ -152,3 +152,51 @@ def test_cyclegan_grad_sync_hook_equals_big_batch(split):
     assert all(r[1] < 5e-6 for r in res), res
     assert len(res[0][2]) == (3 if split else 2) * 2      # hook invocations: per optimiser, per iteration
     assert res[0][3] == res[1][3]
+
+
+def _comm_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from raygun_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    ints = parallel.all_gather_ints(list(range(rank)))                     # ragged: rank r contributes r values (rank 0 none)
+    t = torch.arange(rank * 2, dtype=torch.int64).reshape(rank, 2) + 100 * rank
+    cat = parallel.all_gather_cat(t)
+    up, down = parallel.neighbor_exchange(torch.full((2, 3), float(rank)) if rank > 0 else None,
+                                          torch.full((2, 3), float(rank) + 0.5) if rank < world - 1 else None)
+    out.put((rank, ints, cat.tolist(), None if up is None else float(up[0, 0]), None if down is None else float(down[0, 0])))
+    torch.distributed.destroy_process_group()
+
+
+def test_small_exchanges_of_the_sharded_paths():
+    """parallel.all_gather_ints / all_gather_cat / neighbor_exchange (the slab mutex watershed's exchanges), 3 ranks over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ints, cat, up, down in res:
+        assert ints == [[], [0], [0, 1]]
+        assert cat == [[100, 101], [200, 201], [202, 203]]
+        assert up == (None if rank == 0 else rank - 1 + 0.5)            # what rank - 1 sent "to next"
+        assert down == (None if rank == 2 else float(rank + 1))          # what rank + 1 sent "to prev"
+
+
+def test_launch_ranks_supervises_its_children():
+    """parallel.launch_ranks: a failing rank ends its siblings at once (no hang in a collective), a timeout ends everything with
+    124, a rank killed by a signal is reported as 128 + signal."""
+    import sys
+    import time
+    from raygun_amd.parallel import launch_ranks
+    t = time.time()
+    rc = launch_ranks([sys.executable, "-c", "import os,sys,time; (sys.exit(3) if os.environ['RANK']=='1' else time.sleep(60))"], 3)
+    assert rc == 3 and time.time() - t < 20
+    t = time.time()
+    assert launch_ranks([sys.executable, "-c", "import time; time.sleep(60)"], 2, timeout=1.0) == 124 and time.time() - t < 20
+    assert launch_ranks([sys.executable, "-c", "import os; assert os.environ['WORLD_SIZE']=='2' and os.environ['MASTER_ADDR']=='127.0.0.1'"], 2) == 0
+    rc = launch_ranks([sys.executable, "-c", "import os,signal,time; (os.kill(os.getpid(), signal.SIGKILL) if os.environ['RANK']=='0' else time.sleep(60))"], 2)
+    assert rc == 128 + 9

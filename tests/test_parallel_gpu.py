@@ -1,75 +1,35 @@
-"""Data parallelism on real GPUs over RCCL (skipped on a 1-GPU box): DP(2) x k steps == 1-GPU big-batch run, for the U-Net
-affinity system (GradSync.attach: all-reduces overlapped with backward) and the Link CycleGAN (grad_sync hook)."""
-import os
-import socket
-
+"""The RCCL variant of tests/test_multirank_gpu.py's data-parallel and sharded-segmentation cases: one rank per GPU, backend
+"nccl" (= RCCL over xGMI).  Needs >= 2 GPUs; on a one-GPU box the same code paths run over gloo in test_multirank_gpu.py."""
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
+
+from tests.test_multirank_gpu import NB8, _dp_cyclegan, _dp_unet, _seg_rank, _slab_case, run_ranks
 
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+def _need(n):
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs {n} GPUs (the gloo twin in test_multirank_gpu.py covers one-GPU boxes)")
 
 
-def _mtlsd(dev):
-    from raygun_amd import synth
-    from raygun_amd.torch.models import MTLSDModel
-    kw = {"input_nc": 1, "ngf": 4, "fmap_inc_factor": 2, "downsample_factors": [(2, 2, 2)], "constant_upsample": True}
-    m = MTLSDModel(unet_kwargs=kw, num_affs=3)
-    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 5))
-    return m.to(dev)
+def test_dp2_rccl_unet_equals_big_batch():
+    _need(2)
+    res = run_ranks(_dp_unet, 2, backend="nccl")
+    assert res[0][1] == res[1][1] and max(r[0] for r in res) <= 2e-2, res
 
 
-def _mtlsd_steps(m, raw, k, sync):
-    from raygun_amd import synth
-    from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
-    from raygun_amd.torch.optimizers import FusedAdam
-    opt = FusedAdam(m.parameters(), lr=1e-3)
-    lf = WeightedMSELoss_MTLSD()
-    if sync is not None:
-        sync.attach(m.parameters())
-    for it in range(k):
-        opt.zero_grad(set_to_none=True)
-        affs, lsds = m(raw)
-        ga = torch.from_numpy(synth.uniform(tuple(affs.shape[1:]), 60, 0, 1)).to(raw.device).expand_as(affs)
-        gl = torch.from_numpy(synth.uniform(tuple(lsds.shape[1:]), 61, 0, 1)).to(raw.device).expand_as(lsds)
-        lf(lsds, gl, torch.ones_like(lsds), affs, ga, torch.ones_like(affs)).backward()
-        if sync is not None:
-            sync(list(m.parameters()))
-        opt.step()
-    return [p.detach().float().cpu() for p in m.parameters()]
+def test_dp2_rccl_link_cyclegan_equals_big_batch():
+    _need(2)
+    res = run_ranks(_dp_cyclegan, 2, backend="nccl")
+    assert res[0][1] == res[1][1] and max(r[0] for r in res) <= 0.15 and max(r[3] for r in res) <= 0.02, [(r[0], r[3]) for r in res]
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
-    from raygun_amd import parallel, synth
-    rank, local, world = parallel.init_from_env(backend="nccl")
-    dev = torch.device("cuda", local)
-    raw = torch.from_numpy(synth.uniform((world, 1, 36, 36, 36), 9)).to(dev)
-    got = _mtlsd_steps(_mtlsd(dev), raw[rank:rank + 1], 3, parallel.GradSync())
-    ref = _mtlsd_steps(_mtlsd(dev), raw, 3, None) if rank == 0 else None
-    err = max(float((a - b).abs().max() / (b.abs().max() + 1e-12)) for a, b in zip(got, ref)) if rank == 0 else 0.0
-    out.put((rank, err, [float(p.double().sum()) for p in got]))
-    torch.distributed.destroy_process_group()
-
-
-def test_dp2_equals_big_batch_unet():
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert res[0][2] == res[1][2]                 # identical weights on both ranks (bitwise: same reduced gradients, same Adam)
-    assert res[0][1] <= 2e-2, res                 # vs big batch: bf16 activations, batch-2 kernels vs two batch-1 runs
+def test_segment_slabs_rccl_two_ranks_bit_exact():
+    _need(2)
+    from oracle import mws as O
+    shape, parts = (48, 40, 44), [0, 24, 48]
+    labs = run_ranks(_seg_rank, 2, shape, parts, None, (2, 2, 2), True, backend="nccl")
+    w, mask = _slab_case(shape, 11, True)
+    assert (np.concatenate(labs, 0) == O.slab_mws(w, NB8, 3, (2, 2, 2), mask, parts)).all()

@@ -68,6 +68,36 @@ def test_blockwise_equals_whole_volume():
 
 
 @pytest.mark.gpu
+def test_f16_overflow_falls_back_to_bf16_per_block():
+    """IEEE-half storage (the block runner's default) overflows at 65504 where the fp32 reference and bf16 stay finite: a block
+    with a non-finite output is predicted again with bf16 storage (and recorded), so the result equals the bf16 run; with bf16
+    storage itself a non-finite output raises."""
+    from raygun_amd.torch.networks import UNet
+    dev = torch.device("cuda")
+    net = UNet(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True)
+    sd = synth.fill_state_dict(net.state_dict(), 3)
+    last = [k for k in sd if k.endswith("weight")][-1]
+    sd[last] = sd[last] * 3e6                      # activations of the last layer ~1e5-1e6: beyond half's range, fine for bf16
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    vol = (synth.uniform((60, 60, 60), 4, 0, 1) * 255).astype(np.uint8)
+    ref, n = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, precision="bf16")
+    assert np.isfinite(ref[0]).all() and np.abs(ref[0]).max() > 65504
+    del P.FALLBACK_BLOCKS[:]
+    got, n = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, precision="f16")
+    assert len(P.FALLBACK_BLOCKS) >= 1 and np.isfinite(got[0]).all()
+    redone = np.zeros(ref[0].shape[1:], bool)
+    for bi in P.FALLBACK_BLOCKS:
+        z, y, x = P.enumerate_blocks(vol.shape, *P.roi_geometry(3, [36] * 3, [20] * 3))[bi]
+        redone[z:z + 20, y:y + 20, x:x + 20] = True
+    assert np.array_equal(got[0][:, redone], ref[0][:, redone])
+    sd[last] = sd[last] * float("inf")
+    net.load_state_dict(sd)
+    with pytest.raises(FloatingPointError):
+        P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, precision="bf16")
+
+
+@pytest.mark.gpu
 def test_on_disk_flow_equals_in_memory(tmp_path):
     """predict_zarr (zarr source -> zarr destinations chunked by the write ROI, offset / resolution carried over) gives the
     same voxels as predict_volume on the in-memory array; then mutex_segment reads the predicted affinities from the
