@@ -23,24 +23,7 @@ __device__ __forceinline__ void s4_impl(F&& f, std::integer_sequence<int, Is...>
 template <int N, class F>
 __device__ __forceinline__ void s4for(F&& f) { s4_impl(f, std::make_integer_sequence<int, N>{}); }
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-struct Igemm4Args {
-  const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
-  int N, ID, IH, IW;
-  int RD, RH, RW;
-  int TD, TH, TW;
-  int rs[3], tb[3], ts[3], os[3], oo[3];
-  long xsn, xsd, xsh, xsw;
-  long ysn, ysd, ysh, ysw;
-  int cink, cin_lanes, cout, cout_lanes, wrows;
-  int act; float slope;
-  long M;
-  int tiles_m, tiles_n;
-  unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
-  int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
-  int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
-  int nbatch; long xbatch, wbatch, ybatch;  // batched GEMM (rg_gemm_batched): element strides between the problems; no split-K
-};
+#include "igemm_args.h"
 
 typedef __attribute__((address_space(3))) void* lptr4_t;
 template <int OFF>
@@ -441,6 +424,8 @@ bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
 int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
+bool rg_igemm5_ok(const Igemm4Args& a, bool flat);
+int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st);
 struct Igemm4Batch { int n; long xs, ws, ys; };
 static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                              void* workspace, size_t ws_bytes, const Igemm4Batch* bt);
@@ -482,6 +467,7 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
+  if (rg_igemm5_ok(a, flat != 0)) return rg_launch_igemm5(a, check, st);   // 256 x 288 tiles, both operands through LDS by LDS-DMA (gemm5.hip)
   if (flat && rg_halo16_ok(X, Y, p) && !rg_opt(RG_OPT_NO_HALO)) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
   if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !rg_opt(RG_OPT_NO_THIN)) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;
@@ -529,6 +515,7 @@ extern "C" int rg_gemm_batched(const void* A, const void* W, void* Cm, int64_t b
   const int kp = round_up(k, 64);
   if (a_rs < kp || (a_rs & 7) || c_rs < round_up(n, 8) || (c_rs & 7) || m >= (1L << 31) || batches >= (1 << 16))
     RG_FAIL(RG_ERR_BAD_SHAPE, "gemm_batched: row strides must cover k rounded up to 64 / n rounded up to 8 and be multiples of 8");
+
   CL5 X, Y;
   X.p = (bf16_t*)A; X.N = 1; X.C = k; X.D = 1; X.H = 1; X.W = (int)m; X.lanes = kp; X.sn = m * a_rs; X.sd = m * a_rs; X.sh = m * a_rs; X.sw = a_rs;
   Y.p = (bf16_t*)Cm; Y.N = 1; Y.C = n; Y.D = 1; Y.H = 1; Y.W = (int)m; Y.lanes = round_up(n, 8); Y.sn = m * c_rs; Y.sd = m * c_rs; Y.sh = m * c_rs; Y.sw = c_rs;

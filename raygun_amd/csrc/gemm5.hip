@@ -1,0 +1,285 @@
+// gemm5 — 256 x 288 x 64 tiles, 8 waves, BOTH operands through LDS by LDS-DMA in full 128-byte lines.
+//
+// igemm4 (conv4.hip) feeds the activation operand straight from global memory into MFMA fragments: 16 rows x 64 B per
+// wave-instruction.  rocprofv3 on the U-Net step (profiles/r03a_unet_pmc_mfma.csv) shows what that costs: the MFMA pipe of
+// igemm4<4,9> is 37-44 % busy while its waves spend 50 % of their cycles stalled at issue — the vector-memory path, not the
+// matrix pipe, paces the loop (fragment-shaped loads keep the texture addresser busy twice as long per byte as full lines).
+// Here every global byte moves as part of a whole 128-byte line, lands in LDS without passing a register
+// (`buffer_load_dwordx4 ... offen lds`, 1 KiB per wave-instruction; out-of-range lanes store ZEROS — probed on gfx950,
+// tools/kbench/ldsdma_probe.hip — so row tails and zero padding stay branch-free) and is shared by the waves that need it:
+//
+//   workgroup   8 waves = 4 (rows, 64 each) x 2 (columns, 144 each); wave tile 64 x 144 = 4 x 9 MFMA 16x16x32 accumulators
+//   LDS         2 stages x (A 256 rows + B 320 rows) x 128 B = 144 KiB; 16-byte slot of piece p in row R: p ^ ((R >> 1) & 7)
+//               (conflict-free ds_read_b128 for 16 consecutive rows); the DMA writes lane-linearly, so the swizzle is applied
+//               to the SOURCE piece each lane fetches
+//   K-tile      64 deep = 2 column groups x 2 k-halves = 4 phases of 20 / 20 / 16 / 16 MFMAs per wave; a phase is
+//                 [fragment reads + DMA issue] lgkmcnt(0) s_barrier [MFMA cluster] s_barrier
+//               and the two column groups (waves 0-3 / 4-7: one of each per SIMD) run ONE barrier apart, so on every SIMD one
+//               wave issues MFMAs while the other reads fragments and feeds the DMA queue
+//   prefetch    B(t+1) is issued in phases 0-1 of tile t into the stage tile t-1 was read from, A(t+2) in phases 2-3 into THIS
+//               stage, whose A part is in registers by then (all those reads were retired by lgkmcnt(0) in front of a barrier
+//               every wave has passed); every wave waits for its own pieces with ONE counted vmcnt per tile, in phase 3, in front
+//               of a barrier; tile t+1 is first read one barrier later by the leading group, two by the trailing one
+//
+// C[b][m][n] = sum_k A[b][m][k] * W[b][n][k]  (+ bias[n], activation), 16-bit storage type of this build, fp32 accumulation.
+#include "igemm_args.h"
+#include <utility>
+
+typedef int g5_i32x4 __attribute__((ext_vector_type(4)));
+
+#define G5_BM 256
+#define G5_BN 288
+#define G5_BROWS 320                       // B rows staged per tile (5 DMA instructions of 64 rows; rows 288..319 are never fetched or read)
+#define G5_STAGE ((G5_BM + G5_BROWS) * 128) // bytes per stage
+#define G5_OOB 0x80000000u
+
+__device__ __forceinline__ g5_i32x4 g5_rsrc(const void* base, unsigned nrec) {
+  const unsigned long b = (unsigned long)base;
+  return (g5_i32x4){(int)(unsigned)b, (int)((b >> 32) & 0xffffu), (int)nrec, 0x00020000};
+}
+// one LDS-DMA wave-instruction: lane l's 16 bytes at (rsrc + voff + soff) -> LDS[lds_base + 16 l]; zeros when out of range (voff +
+// soff is range-checked as a whole on gfx950).  M0 (the destination base) is written in the statement that uses it (s_nop 0: SALU
+// write of M0 -> LDS-DMA needs one wait state); nothing else in this kernel uses M0 (no movrel / GWS / sendmsg): not restored.
+__device__ __forceinline__ void g5_dma(unsigned lds_base, g5_i32x4 rsrc, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void g5_ldr(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
+
+template <class F, int... Is>
+__device__ __forceinline__ void g5_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void g5for(F&& f) { g5_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// The implicit-GEMM form (same row / tap / output maps and packed-weight format as igemm4, conv4.hip): A rows are output voxels, a
+// K-tile is one 64-channel chunk of one tap (chunk outer, tap inner: consecutive tiles read neighbouring voxels); the tap's byte
+// offset is added to each of the thread's 4 row offsets, rows / taps / channel lanes outside the tensor become out-of-range offsets
+// (zeros).  rg_gemm_batched's problems are the 1x1x1-tap case with a batch index in the grid.
+template <bool CHECK>
+__global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char g5_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;     // row group (64 rows), column group (144 columns); column group = stagger group
+  const int nwg = a.tiles_m * a.tiles_n * a.ksplit * a.nbatch;
+  int bid = blockIdx.x;
+  { const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+  const int batch = bid / (a.tiles_m * a.tiles_n * a.ksplit); bid -= batch * (a.tiles_m * a.tiles_n * a.ksplit);
+  const int split = bid / (a.tiles_m * a.tiles_n); bid -= split * (a.tiles_m * a.tiles_n);
+  const int tile_n = bid / a.tiles_m, tile_m = bid - tile_n * a.tiles_m;
+  const long m0 = (long)tile_m * G5_BM;
+  const int n0 = tile_n * G5_BN;
+  const bf16_t* const xbase = a.x + batch * a.xbatch;
+  const bf16_t* const wbase = a.w + batch * a.wbatch;
+  bf16_t* const ybase = a.y + batch * a.ybatch;
+  const g5_i32x4 ra = g5_rsrc(xbase, a.xbytes), rw = g5_rsrc(wbase, a.wbytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)g5_lds;
+  const int ntaps = a.TD * a.TH * a.TW, nchunk = a.cink >> 6;
+  // K range of this workgroup in K-tiles (tile = chunk * ntaps + tap): everything, or the split's share
+  const int kunits = nchunk * ntaps, kper = (kunits + a.ksplit - 1) / a.ksplit;
+  const int ku0 = split * kper, ku1 = ku0 + kper < kunits ? ku0 + kper : kunits;
+  const int nk = ku1 > ku0 ? ku1 - ku0 : 0;
+
+  // ---- DMA pieces of this thread: instruction i covers tile rows i*64 + wave*8 + (lane>>3); the lane fetches the piece that
+  // belongs in ITS slot of the swizzled image
+  const int drow = wave * 8 + (lane >> 3);                       // row within a 64-row instruction
+  const int dpiece = (lane & 7) ^ ((drow >> 1) & 7);             // (i*64 does not change (row >> 1) & 7)
+  int rd0[4], rh0[4], rw0[4]; unsigned va[4], vb[5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + i * 64 + drow;
+    const bool v = m < a.M;
+    long t = v ? m : 0;
+    const int rw_ = (int)(t % a.RW); t /= a.RW;
+    const int rh_ = (int)(t % a.RH); t /= a.RH;
+    const int rd_ = (int)(t % a.RD); t /= a.RD;
+    rd0[i] = rd_ * a.rs[0] + a.tb[0]; rh0[i] = rh_ * a.rs[1] + a.tb[1]; rw0[i] = rw_ * a.rs[2] + a.tb[2];
+    // tap offsets are added later and may be negative: valid rows stay inside [0, 2^30), parked rows stay out of range
+    va[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + dpiece * 8) * 2) : G5_OOB;
+    if (!v) { rd0[i] = rh0[i] = rw0[i] = -(1 << 20); }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = i * 64 + drow, n = n0 + r;
+    vb[i] = (r < G5_BN && n < a.wrows) ? (unsigned)(((long)n * ntaps * a.cink + dpiece * 8) * 2) : G5_OOB;
+  }
+  const unsigned dma_lds = lds0 + wave * 1024;                   // + stage * G5_STAGE + (A: i * 8192 | B: 32768 + i * 8192)
+
+  // ---- producer odometers: A runs two K-tiles ahead of the MFMAs, B one
+  int akd, akh, akw, achunk, btap, bchunk;
+  { const int c0 = ku0 / ntaps, t0 = ku0 - c0 * ntaps; achunk = bchunk = c0; btap = t0; akw = t0 % a.TW; akh = (t0 / a.TW) % a.TH; akd = t0 / (a.TW * a.TH); }
+  int a_off = 0, a_od = 0, a_oh = 0, a_ow = 0; bool a_cok = true;      // the tile whose A pieces are being issued
+  auto prep_a = [&]() {          // offsets of the next A tile; advances the odometer
+    a_od = akd * a.ts[0]; a_oh = akh * a.ts[1]; a_ow = akw * a.ts[2];
+    a_off = ((int)(a_od * a.xsd + a_oh * a.xsh + a_ow * a.xsw) + achunk * 64) * 2;
+    a_cok = achunk * 64 + dpiece * 8 < a.cin_lanes;
+    ++akw;
+    const int cw = akw == a.TW; akw = cw ? 0 : akw; akh += cw;
+    const int ch = akh == a.TH; akh = ch ? 0 : akh; akd += ch;
+    const int cd = akd == a.TD; akd = cd ? 0 : akd; achunk += cd;
+  };
+  auto dma_a = [&](int stage, auto I) {
+    constexpr int i = decltype(I)::value;
+    bool ok = a_cok;
+    if (CHECK) ok = ok & ((unsigned)(rd0[i] + a_od) < (unsigned)a.ID) & ((unsigned)(rh0[i] + a_oh) < (unsigned)a.IH) & ((unsigned)(rw0[i] + a_ow) < (unsigned)a.IW);
+    g5_dma(__builtin_amdgcn_readfirstlane(dma_lds + stage * G5_STAGE + i * 8192), ra, ok ? va[i] + (unsigned)a_off : G5_OOB, 0);
+  };
+  int b_soff = 0;
+  auto prep_b = [&]() { b_soff = (btap * a.cink + bchunk * 64) * 2; ++btap; const int c = btap == ntaps; btap = c ? 0 : btap; bchunk += c; };
+  auto dma_b = [&](int stage, auto I) {
+    constexpr int i = decltype(I)::value;
+    g5_dma(__builtin_amdgcn_readfirstlane(dma_lds + stage * G5_STAGE + G5_BM * 128 + i * 8192), rw, vb[i], b_soff);
+  };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>; using C4 = std::integral_constant<int, 4>;
+
+  // ---- fragment addresses: lane (fr, fg) reads piece h*4 + fg of row base + fr; slot = piece ^ (fr >> 1); k-half 1 = address ^ 64
+  const int fr = lane & 15, fg = lane >> 4;
+  const unsigned flane = fr * 128 + ((fg ^ (fr >> 1)) << 4);
+  const unsigned fa0 = lds0 + wm * (64 * 128) + flane;                        // A fragments of this wave, stage 0, k-half 0
+  const unsigned fb0 = lds0 + G5_BM * 128 + wn * (144 * 128) + flane;         // B fragments
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: A(0), B(0) -> stage 0, A(1) -> stage 1 (stays in flight)
+  const bool two = nk > 1;
+  prep_a(); dma_a(0, C0{}); dma_a(0, C1{}); dma_a(0, C2{}); dma_a(0, C3{});
+  prep_b(); dma_b(0, C0{}); dma_b(0, C1{}); dma_b(0, C2{}); dma_b(0, C3{}); dma_b(0, C4{});
+  if (two) {
+    prep_a(); dma_a(1, C0{}); dma_a(1, C1{}); dma_a(1, C2{}); dma_a(1, C3{});
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wn) __builtin_amdgcn_s_barrier();      // the trailing group runs one barrier behind (matched after the loop)
+
+  // Phase order within a K-tile: (columns 0-4, k-half 0) (columns 0-4, k-half 1) (columns 5-8, k-half 0) (columns 5-8, k-half 1).
+  // The A fragments of BOTH k-halves are in registers after phase 1, so the A part of this stage is free two phases before the B
+  // part: the DMA of A(t+2) is issued in phases 2-3 of tile t (a whole tile ahead of its first read), the DMA of B(t+1) in phases
+  // 0-1 — 3 / 2 / 2 / 2 DMA instructions per phase instead of 5 / 4 / 0 / 0 (an LDS-DMA instruction costs its wave 60-180
+  // cycles of issue; the read segment must stay shorter than the other group's MFMA cluster: 926 -> 1022 TFLOP/s on the Winograd
+  // GEMMs).  One counted wait per tile, in phase 3: vmcnt(4) = everything but the 4 youngest pieces (A(t+2)) has landed, i.e.
+  // A(t+1) and B(t+1).
+  bf16x8 af[8], bf[5];
+  for (int t = 0; t < nk; ++t) {
+    const int stage = t & 1;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    const unsigned sa = fa0 + stage * G5_STAGE, sb = fb0 + stage * G5_STAGE;
+    g5for<4>([&](auto P) {
+      constexpr int p = decltype(P)::value, h = p & 1, jg = p >> 1;
+      constexpr int J0 = jg ? 5 : 0, NJ = jg ? 4 : 5;
+      // ---- read segment
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned aa = sa ^ (h * 64), bb = sb ^ (h * 64);
+      if constexpr (jg == 0) g5for<4>([&](auto I) { g5_ldr<decltype(I)::value * 2048>(af[h * 4 + decltype(I)::value], aa); });
+      g5for<NJ>([&](auto J) { g5_ldr<(J0 + decltype(J)::value) * 2048>(bf[decltype(J)::value], bb); });
+      if constexpr (p == 0) { if (more1) { prep_b(); dma_b(stage ^ 1, C0{}); dma_b(stage ^ 1, C1{}); dma_b(stage ^ 1, C2{}); } }
+      if constexpr (p == 1) { if (more1) { dma_b(stage ^ 1, C3{}); dma_b(stage ^ 1, C4{}); } }
+      if constexpr (p == 2) { if (more2) { prep_a(); dma_a(stage, C0{}); dma_a(stage, C1{}); } }
+      if constexpr (p == 3) {
+        if (more2) { dma_a(stage, C2{}); dma_a(stage, C3{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // every fragment read of this phase has returned (names the registers: the MFMAs below depend on this statement)
+      if constexpr (jg == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[h * 4]), "+v"(af[h * 4 + 1]), "+v"(af[h * 4 + 2]), "+v"(af[h * 4 + 3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]) :: "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) :: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA cluster: column fragments J0 .. J0 + NJ - 1 x the 4 row fragments, k-half h
+      __builtin_amdgcn_s_setprio(1);
+      g5for<NJ>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][J0 + j] = RG_MFMA16(bf[j], af[h * 4 + i], acc[i][J0 + j]);
+      });
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    });
+  }
+  if (!wn) __builtin_amdgcn_s_barrier();     // matches the trailing group's extra barrier
+
+  // ---- epilogue: lane holds columns c .. c+3 of row (lane & 15) of every fragment
+  if (a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the 16-bit store happen in the combine kernel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wm * 64 + i * 16 + fr;
+      if (m >= a.M) continue;
+      float* prow = a.part + ((long)split * a.M + m) * a.cout_lanes;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int c = n0 + wn * 144 + j * 16 + fg * 4;
+        if (c < a.cout_lanes) *(f32x4*)(prow + c) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= a.M) continue;
+    long t = m;
+    const int rw_ = (int)(t % a.RW); t /= a.RW;
+    const int rh_ = (int)(t % a.RH); t /= a.RH;
+    const int rd_ = (int)(t % a.RD); t /= a.RD;
+    bf16_t* yrow = ybase + t * a.ysn + (long)(rd_ * a.os[0] + a.oo[0]) * a.ysd + (long)(rh_ * a.os[1] + a.oo[1]) * a.ysh +
+                   (long)(rw_ * a.os[2] + a.oo[2]) * a.ysw;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int c = n0 + wn * 144 + j * 16 + fg * 4;
+      if (c >= a.cout_lanes) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = 0.f;
+        if (c + r < a.cout) {
+          v = acc[i][j][r] + (a.bias ? a.bias[c + r] : 0.f);
+          v = act_fwd(v, a.act, a.slope);
+        }
+        o[r] = (short)f2bf(v);
+      }
+      *(bf16x4*)(yrow + c) = o;
+    }
+  }
+}
+
+// Heuristic: the 288-column tile must be (nearly) full, the grid must give most CUs a workgroup (one 8-wave workgroup per CU), and K
+// must be long enough to amortise the two-tile prologue.  opt = rg_opt(RG_OPT_GEMM5): 0 heuristic, 1 wherever the tiling allows, -1 off.
+bool rg_igemm5_ok(const Igemm4Args& a, bool flat) {
+  const int opt = rg_opt(RG_OPT_GEMM5);
+  if (opt < 0 || flat || (a.wrows % 16) || a.cout_lanes < 8) return false;
+  const int nf = a.wrows / 16;
+  if (nf % 9) return false;                     // columns in 144-column halves
+  if (opt == 1) return true;
+  const long tiles_m = (a.M + G5_BM - 1) / G5_BM, tiles_n = (a.wrows + G5_BN - 1) / G5_BN;
+  const long tiles = tiles_m * tiles_n * a.nbatch;
+  const double fill_n = (double)a.wrows / (double)(tiles_n * G5_BN);
+  const int kunits = (a.cink >> 6) * a.TD * a.TH * a.TW;
+  // whole rounds of 256 workgroups: the last round's fill decides what a coarse tile costs
+  const double rounds = (double)tiles / 256.0, fill_r = rounds / (double)(long)(rounds + 0.999999);
+  const double fmin = opt == 2 ? 0.70 : 0.88;   // (2: also the 432-column layers, one of whose two column tiles is half empty — A/B switch)
+  return fill_n >= fmin && kunits >= 8 && tiles >= 150 && fill_r >= 0.70;
+}
+
+int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st) {
+  a.tiles_m = (int)((a.M + G5_BM - 1) / G5_BM);
+  a.tiles_n = (a.wrows + G5_BN - 1) / G5_BN;
+  a.ksplit = 1; a.part = nullptr;
+  static rg_device_latch attr;
+  rg_once_per_device(&attr, [] {
+    hipFuncSetAttribute((const void*)igemm5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+  });
+  rg_set_kernel_name("igemm5_kernel<%d>", (int)check);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.nbatch));
+  if (check) hipLaunchKernelGGL(igemm5_kernel<true>, grid, dim3(512), 2 * G5_STAGE, st, a);
+  else hipLaunchKernelGGL(igemm5_kernel<false>, grid, dim3(512), 2 * G5_STAGE, st, a);
+  return RG_OK;
+}

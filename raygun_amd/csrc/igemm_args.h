@@ -1,0 +1,22 @@
+// Launch arguments shared by the implicit-GEMM convolution kernels (conv4.hip: igemm4 and its thin variants; gemm5.hip: igemm5).
+#pragma once
+#include "common.h"
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct Igemm4Args {
+  const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
+  int N, ID, IH, IW;
+  int RD, RH, RW;
+  int TD, TH, TW;
+  int rs[3], tb[3], ts[3], os[3], oo[3];
+  long xsn, xsd, xsh, xsw;
+  long ysn, ysd, ysh, ysw;
+  int cink, cin_lanes, cout, cout_lanes, wrows;
+  int act; float slope;
+  long M;
+  int tiles_m, tiles_n;
+  unsigned xbytes, wbytes;  // extents for the buffer descriptors (< 2^30)
+  int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
+  int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
+  int nbatch; long xbatch, wbatch, ybatch;  // batched GEMM (rg_gemm_batched): element strides between the problems; no split-K
+};
+

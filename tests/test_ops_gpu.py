@@ -670,3 +670,58 @@ def test_winograd_operands_follow_the_optimizer(monkeypatch):
         monkeypatch.delenv("RAYGUN_AMD_WINOGRAD")
         assert relerr(y1, y0) > 5e-2, "the step did not change the output: stale transformed weights"
         assert relerr(y1, y1d) <= TOL, relerr(y1, y1d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,k,stride,pad,act,n", [
+    (64, 144, (9, 10, 11), 3, 1, 0, "relu", 1),        # one half-empty 288-column tile, ragged row tile
+    (184, 288, (12, 9, 10), 3, 1, 1, "leaky", 2),      # ragged channel chunk (184 = 2 chunks + 56 lanes), zero padding (CHECK), N = 2
+    (432, 432, (8, 8, 9), 3, 1, 0, "none", 1),         # the U-Net's 432-channel layers: 7 chunks, 1.5 column tiles
+    (128, 576, (10, 10, 10), 2, 1, 0, "relu", 1),      # 2^3 taps (the sub-pixel layers)
+    (64, 288, (13, 12, 14), 3, 2, 1, "sigmoid", 1),    # strided rows
+])
+def test_igemm5_lds_dma_conv_forward_and_backward_data(cin, cout, sp, k, stride, pad, act, n):
+    """gemm5.hip igemm5_kernel (256 x 288 tiles, both operands through LDS by LDS-DMA, staggered wave groups) forced on for
+    shapes that exercise its row / channel / column tails, zero padding, strides, tap odometers over several chunks and the
+    backward-data pass (flipped taps, full correlation): against torch fp32 on the CPU, and identical to what igemm4 computes."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((n, cin) + sp, 91); w0 = rnd((cout, cin, k, k, k), 92, -0.05, 0.05); b0 = rnd((cout,), 93)
+    afn = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    xr = x0.clone().requires_grad_()
+    yr = afn(F.conv3d(xr, w0, b0, stride=stride, padding=pad))
+    go = rnd(tuple(yr.shape), 94)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    outs = {}
+    for opt in (1, -1):
+        with ops.option("RG_GEMM5", opt):
+            xd = x0.clone().to(dev).requires_grad_()
+            y = ops.conv3d(xd, w0.to(dev), b0.to(dev), stride, pad, act, 0.2)
+            name = _lib.lib().rg_last_kernel_name().decode()
+            assert ("igemm5" in name) == (opt == 1), name
+            (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+            assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL, (opt, relerr(y, yr), relerr(gx, gxr))
+            outs[opt] = (y.float().cpu(), gx.float().cpu())
+    assert relerr(outs[1][0], outs[-1][0]) <= 2 ** -7 and relerr(outs[1][1], outs[-1][1]) <= 2 ** -7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,m,k,n", [(2, 300, 200, 288), (3, 700, 2592, 576), (1, 257, 64, 144), (2, 1000, 448, 432)])
+def test_gemm_batched_on_igemm5(B, m, k, n):
+    """rg_gemm_batched (the Winograd path's 64 transform-domain GEMMs) on igemm5 and on igemm4 against torch.matmul in fp32."""
+    import ctypes as C
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    L = _lib.lib()
+    kp, nr, ms_ = (k + 63) // 64 * 64, (n + 31) // 32 * 32, (n + 63) // 64 * 64
+    A = torch.zeros(B, m, kp, device=dev, dtype=torch.bfloat16); A[:, :, :k] = rnd((B, m, k), 95).to(dev).to(torch.bfloat16)
+    W = torch.zeros(B, nr, kp, device=dev, dtype=torch.bfloat16); W[:, :n, :k] = rnd((B, n, k), 96, -0.05, 0.05).to(dev).to(torch.bfloat16)
+    ref = torch.matmul(A[:, :, :k].float(), W[:, :n, :k].float().transpose(1, 2)).cpu()
+    for opt in (1, -1):
+        Cm = torch.full((B, m, ms_), float("nan"), dtype=torch.bfloat16, device=dev)
+        with ops.option("RG_GEMM5", opt):
+            _lib.check(L.rg_gemm_batched(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(Cm.data_ptr()), B, m, k, n, kp, m * kp,
+                                         nr * kp, ms_, m * ms_, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rg_gemm_batched")
+        assert ("igemm5" in L.rg_last_kernel_name().decode()) == (opt == 1)
+        got = Cm[:, :, :n].float().cpu()
+        assert float((got - ref).abs().max() / ref.abs().max()) <= 8e-3

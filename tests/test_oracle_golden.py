@@ -123,6 +123,30 @@ def test_cyclegan_3d_link_and_split_steps():
     _cyclegan("cyclegan_step_split_3d32", 3, (1, 1, 32, 32, 32), g3, d3, True)
 
 
+def test_cyclegan_3d_full_width_ngf64_first_iteration():
+    """BASELINE config 2 at its real width (ngf 64, 6 blocks, PatchD ngf 64) on 64^3: the oracle's first link iteration against the
+    reference-generated fixture (one iteration here, ~40 s on 8 cores; make_golden.py asserted both while writing it)."""
+    fx = np.load(os.path.join(G, "cyclegan_step_link_3d64_ngf64.npz"))
+    ref = json.loads(str(fx["loss_dicts"]))[0]
+    g3 = dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same")
+    d3 = dict(input_nc=1, ngf=64, n_layers=3, kw=4)
+    model, loss, _ = O.build_cyclegan(3, g3, d3, split=False, g_lr=1e-4, d_lr=1e-4, betas=(0.5, 0.999), init=False)
+    for i, net in enumerate([model.netG1, model.netG2, loss.netD1, loss.netD2]):
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i))
+    A = T(synth.uniform((1, 1, 64, 64, 64), 90)); B = T(synth.uniform((1, 1, 64, 64, 64), 91))
+    _, outs = O.cyclegan_step(model, loss, A, B)
+    for k, v in ref.items():
+        assert abs(float(loss.loss_dict[k]) - v) <= 2e-4 * max(abs(v), 1e-2), k
+    idx = fx["sample_idx"]
+    for i, nm in enumerate(["fake_B", "cycled_B", "fake_A", "cycled_A"]):
+        a, b = outs[i].detach().reshape(-1)[idx].numpy(), fx["sample_" + nm][0]
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max(), nm
+    gs = json.loads(str(fx["grad_sums"]))[0]
+    for net, name in ((model.netG1, "G1"), (loss.netD2, "D2")):
+        for n, p in net.named_parameters():
+            assert abs(float(p.grad.double().abs().sum()) - gs[name][n][1]) <= 2e-4 * gs[name][n][1], (name, n)
+
+
 def test_cyclegan_2d_256_plumbing_config0():
     """BASELINE config[0]: 2-D CycleGAN 256x256 single train step on the PyTorch CPU path (split loss, 2 iterations)."""
     IN2 = functools.partial(torch.nn.InstanceNorm2d)
