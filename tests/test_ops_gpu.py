@@ -725,3 +725,35 @@ def test_gemm_batched_on_igemm5(B, m, k, n):
         assert ("igemm5" in L.rg_last_kernel_name().decode()) == (opt == 1)
         got = Cm[:, :, :n].float().cpu()
         assert float((got - ref).abs().max() / ref.abs().max()) <= 8e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,k,pad,n", [
+    (144, 144, (6, 9, 40), 3, 0, 1),      # a = 144 (FA 9), b = 128 + 16 (two b-tiles), line order, ragged W chunk
+    (432, 288, (5, 19, 19), 3, 0, 1),     # flat-plane order (17 x 17 outputs of a 19 x 19 plane), 4 b-tiles of which the last holds 48 channels
+    (200, 256, (7, 10, 34), 3, 1, 2),     # FA 8 with a ragged a-tile (200 -> 2 x 128), zero padding, N = 2
+    (256, 160, (6, 12, 33), 2, 0, 1),     # 2 taps along W (the sub-pixel layers)
+])
+def test_wgrad_kwd_lds_dma_weight_gradient(cin, cout, sp, k, pad, n):
+    """wgrad_kwd_kernel (wgrad.hip: kw-reuse weight gradient with both tiles staged by LDS-DMA, 4-stage ring, staggered wave groups)
+    against torch fp32 on the CPU and against the producer-wave kernel (the default; RG_KWD = 1 selects this one), for both row orders, both a-tile
+    widths, 2 and 3 W taps, ragged tiles and unit counts that are not multiples of the ring."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((n, cin) + sp, 97); w0 = rnd((cout, cin, k, k, k), 98, -0.05, 0.05)
+    xr = x0.clone(); wr = w0.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, None, padding=pad)
+    go = rnd(tuple(yr.shape), 99)
+    (gwr,) = torch.autograd.grad(yr, wr, go)
+    outs = {}
+    for opt in (1, 0):
+        with ops.option("RG_KWD", opt):
+            wd = w0.clone().to(dev).requires_grad_()
+            y = ops.conv3d(x0.to(dev), wd, None, 1, pad, "none")
+            ops.profile_start()
+            (gw,) = torch.autograd.grad(y, wd, go.to(dev).to(y.dtype))
+            names = list(ops.profile_stop())
+            assert any("wgrad_kwd" in nm for nm in names) == (opt == 1), names
+            assert relerr(gw, gwr) <= TOL, (opt, relerr(gw, gwr))
+            outs[opt] = gw.float().cpu()
+    assert relerr(outs[1], outs[0]) <= 2 ** -9
