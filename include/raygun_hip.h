@@ -280,6 +280,25 @@ int rg_mws_relabel(int64_t* labels, const int64_t* lut, int64_t n, rg_stream s);
  * compressor) -> dst; returns the number of bytes written or -1 on malformed input / a too small buffer. */
 int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
 
+/* ---- train-time target generation of the MTLSD system (reference: src/raygun/io/MTLSDDataPipe.py:99-131; gunpowder's AddAffinities /
+ * BalanceLabels and lsd's AddLocalShapeDescriptor restated — parity unpinned against those packages, oracle/targets.py).  Dense device
+ * arrays: labels int32 (Z,Y,X), label mask uint8, outputs float32 (channels, oz, oy, ox) over the ROI [out_offset, out_offset + out_shape).
+ * rg_add_affinities: aff[e][p] = labels[p] == labels[p + nhood[e]] and both > 0 (0 where p + nhood[e] leaves the array); affs_mask (nullable)
+ *   is the same graph of labels_mask.  nhood: n_offsets x 3 int32 on the device.
+ * rg_balance_labels: scale = mask * w[label], w[c] = 1 / 2 / clip(share of class c among the masked-in voxels, clipmin, clipmax); labels are
+ *   the 0 / 1 affinities, mask nullable; workspace: rg_balance_labels_workspace_bytes() bytes.
+ * rg_lsd_targets: 10 channels (mean offset z y x, variance z y x, Pearson zy zx yx, mass) of lsd's Gaussian mode on the grid subsampled by
+ *   `downsample`; wz / wy / wx: the normalised 1-D Gaussian weights (2 radius + 1 floats each, device) of sigma / (voxel size * downsample),
+ *   sub_voxel_size and sigma in world units (host arrays). */
+int rg_add_affinities(const int32_t* labels, const uint8_t* labels_mask, const int32_t* nhood, int32_t n_offsets, const int32_t shape[3],
+                      const int32_t out_offset[3], const int32_t out_shape[3], float* affs, float* affs_mask, rg_stream s);
+int64_t rg_balance_labels_workspace_bytes(void);
+int rg_balance_labels(const float* labels, const float* mask, int64_t n, float clipmin, float clipmax, float* scale, void* workspace,
+                      size_t ws_bytes, rg_stream s);
+int rg_lsd_targets(const int32_t* labels, const int32_t shape[3], const int32_t out_offset[3], const int32_t out_shape[3], int32_t downsample,
+                   const float* wz, const float* wy, const float* wx, const int32_t radius[3], const float sub_voxel_size[3],
+                   const float sigma[3], float* out, rg_stream s);
+
 #ifdef __cplusplus
 }
 #endif

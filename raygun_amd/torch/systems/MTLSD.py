@@ -61,3 +61,9 @@ class MTLSD(BaseSystem):
         na = self.model_kwargs.get("num_affs", 3)
         return {"raw": ((n, 1) + i, -1.0, 1.0), "gt_lsds": ((n, 10) + o, 0.0, 1.0), "lsds_weights": ((n, 10) + o, 1.0, 1.0),
                 "gt_affs": ((n, na) + o, 0.0, 1.0), "affs_weights": ((n, na) + o, 1.0, 1.0)}
+
+    def source_batches(self, rank):
+        """Training from the config's `sources` (io/MTLSDDataPipe.py): random crops + GPU target generation (train/data.py)."""
+        from ..train.data import MTLSDCropBatches
+        return MTLSDCropBatches(self.sources, self.input_shape, self.output_shape, self.neighborhood, self.voxel_size, getattr(self, "lsd_kwargs", None),
+                                self.batch_size, self.device, getattr(self, "random_seed", None) or 42, rank, getattr(self, "random_location_kwargs", None))
