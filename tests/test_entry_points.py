@@ -149,3 +149,33 @@ def test_train_checkpoint_predict_round_trip(tmp_path, monkeypatch):
                               out_dtypes=[np.float32, np.uint8])
     assert n == 8 and np.array_equal(a[...], mem[0]) and np.array_equal(l[...], mem[1]) and mem[0].any()
     assert os.path.exists(os.path.join(zpath, "view_vol.ng"))
+
+
+@pytest.mark.gpu
+def test_train_mtlsd_from_label_sources(tmp_path, monkeypatch):
+    """raygun-train on an MTLSD config WITH `sources` (label volumes) and no "synthetic_data": the batches come from
+    MTLSDCropBatches — random crops + GPU-generated LSDs / affinities / balance weights (reference flow
+    io/MTLSDDataPipe.py:99-131 -> BaseTrain) — for 8 iterations."""
+    from raygun_amd import synth, zarrio
+    from raygun_amd.load_system import load_system
+    monkeypatch.chdir(tmp_path)
+    shape = (56, 56, 56)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 56, (6, 3))
+    g = np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing="ij"), -1).astype(np.float32)
+    lab = (np.linalg.norm(g[..., None, :] - pts, axis=-1).argmin(-1) + 1).astype(np.uint64)
+    raw = ((lab % 3) * 90 + 30 + synth.uniform(shape, 5, 0, 20)).astype(np.uint8)          # raw correlates with the segments
+    zpath = str(tmp_path / "gt.zarr")
+    for name, arr in (("volumes/raw", raw), ("volumes/labels", lab), ("volumes/mask", np.ones(shape, np.uint8))):
+        zarrio.prepare_ds(zpath, name, shape, (4, 4, 4), arr.dtype, write_size=(28, 28, 28), compressor=None)[...] = arr
+    conf = _train_conf(tmp_path, synthetic_data=False, n_diagonals=0, neighborhood=[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                       sources=[{"path": zpath, "raw": "volumes/raw", "labels": "volumes/labels", "labels_mask": "volumes/mask"}],
+                       lsd_kwargs={"sigma": 12, "downsample": 2}, train_kwargs={"checkpoint_basename": "./models/model", "num_epochs": 8,
+                                                                                "save_every": 100, "log_every": 1})
+    s = load_system(conf)
+    s.build_system()
+    from raygun_amd.torch.train.data import MTLSDCropBatches
+    assert isinstance(s.batches, MTLSDCropBatches)
+    loss, outs = s.train()
+    assert torch.isfinite(loss) and set(outs) == {"pred_affs", "pred_lsds"}
+    assert s.trainer.iteration == 8
