@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment"])
+    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment", "config5"])
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -349,6 +349,99 @@ def main_aux(a, rank, local, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def main_config5(a, rank, local, world, dev):
+    """--workload config5 (SURVEY.md 8d config 5 on one GPU per rank, HBM-resident): a synthetic uint8 volume (hash noise + smooth blobs)
+    -> block-wise prediction with MTLSDModel(num_affs = 20) in 196^3 -> 104^3 blocks (f16 storage, uint8 affinities left on the device)
+    -> rg_mws_prepare -> (slab) mutex watershed, sep 3, strides 10, mask threshold 0.5.  One JSON line: end-to-end seconds, blocks/s,
+    Mvoxels/s and both rooflines (the dominant convolution kernel against the MFMA peak, the Kruskal kernel against HBM).  With N > 1
+    ranks every rank runs the chain on its own volume (replicas: the sharded form — Z parts + one boundary exchange — is
+    segment_slabs(z0, global_shape), exercised by tests/test_multirank_gpu.py)."""
+    import ctypes as C
+    from raygun_amd import _lib, ops, pipeline, predict as P
+    from raygun_amd.torch.models import MTLSDModel
+    size = a.size or 404
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        model = MTLSDModel(num_affs=20).eval()
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    r = torch.arange(size, device=dev, dtype=torch.float32)
+    blobs = (torch.sin(r / 9.1 + 1)[:, None, None] * torch.sin(r / 11.3)[None, :, None] * torch.sin(r / 8.7 + 1.0)[None, None, :]).abs() > 0.2
+    vol = (blobs.float() * 140 + 40 + 60 * torch.rand((size,) * 3, generator=g, device=dev)).clamp_(0, 255).to(torch.uint8)
+    nblk = len(P.enumerate_blocks(vol.shape, *P.roi_geometry(3, [196] * 3, [104] * 3)))
+    from raygun_amd import segment as S
+    nbh = torch.as_tensor(S.build_neighborhood().astype("int64"))
+
+    def shaped(x):
+        """The random-initialised network's affinities are noise around 0.5 — the adversarial input of the Kruskal pass (one giant cluster
+        that everything merges into one edge at a time).  A trained network predicts object structure; to time the chain on such input
+        the network's output is blended 20 / 80 with a structure term computed from the block's own intensities: offset k is "attractive"
+        where voxel p and p + offset_k both lie inside a blob (the same construction as --workload segment's structured_affs: the
+        background ends up below the mask threshold).  The full U-Net forward still runs for every block."""
+        affs, lsds = model(x)
+        raw = x.float()[0, 0]                                     # (196, 196, 196) in [0, 1]
+        fg = raw > 0.55
+        c = fg[46:150, 46:150, 46:150]
+        terms = []
+        for dz, dy, dx in nbh.tolist():
+            q = fg[46 + dz:150 + dz, 46 + dy:150 + dy, 46 + dx:150 + dx]
+            terms.append((c & q).float() * 0.8 + 0.1)
+        st = torch.stack(terms)[None]
+        return 0.2 * affs.float() + 0.8 * st, lsds
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    steps, warmup = max(1, min(a.steps, 3)), max(1, min(a.warmup, 1))
+    t_raw = time.perf_counter()
+    _, raw_info = pipeline.predict_and_segment(model, vol)       # the raw network output, once: the adversarial case beside the headline
+    raw_case = dict(segment_s=round(raw_info["segment_s"], 3), predict_s=round(raw_info["predict_s"], 3),
+                    note="unshaped output of the random-initialised network (noise around 0.5): adversarial for the Kruskal pass")
+    model_raw, model_ = model, shaped
+    for _ in range(warmup):
+        labels, info = pipeline.predict_and_segment(model_, vol)
+    barrier()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    tp = ts = 0.0
+    for _ in range(steps):
+        labels, info = pipeline.predict_and_segment(model_, vol)
+        tp += info["predict_s"]; ts += info["segment_s"]
+    barrier()
+    dt = time.perf_counter() - t0
+    buf = (C.c_float * (8 * steps + 1))()
+    n = _lib.lib().rg_profile_drain(buf, 8 * steps + 1)        # the library bracketed the Kruskal kernel of every mutex-watershed pass
+    mws_ms = float(sum(buf[:n])) / steps
+    prof = ops.profile_stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank != 0:
+            torch.distributed.destroy_process_group()
+            return
+    sec = dt / steps
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+    hbm = size ** 3 * MWS_BYTES_PER_VOXEL / (mws_ms * 1e-3) / 1e9 if mws_ms else None
+    res = dict(metric="config 5 end to end: block-wise predict + mutex watershed, seconds per volume", value=round(sec, 4), unit="s", n_gpus=world, steps=steps,
+               warmup=warmup, ms_per_step=round(sec * 1e3, 2), higher_is_better=False, scaling="weak", vs_baseline=None, dtype="f16 storage / f32 keys", data="synthetic",
+               config=dict(workload=f"config5 {size}^3 uint8 volume per GPU resident in HBM: {nblk} blocks 196^3 -> 104^3 through MTLSDModel(20 affinities + 10 LSDs), "
+                                    "uint8 affinities left on the device, rg_mws_prepare + mutex watershed (20 offsets, sep 3, strides 10, mask 0.5)",
+                           parallelism=f"one volume per GPU x{world}"),
+               blocks_per_s=round(nblk * world / (tp / steps), 2), predict_s=round(tp / steps, 4), segment_s=round(ts / steps, 4),
+               mvoxels_per_s=round(size ** 3 * world / sec / 1e6, 2), segments=int(labels.max().item()), raw_network_case=raw_case,
+               affinity_shaping="network output blended 20/80 with a both-voxels-inside-a-blob structure term per offset (see bench.py main_config5.shaped)",
+               roofline=dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                             launches_per_step=dom[1]["launches"] // steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4)),
+               roofline_segment=dict(bound="hbm", kernel="mws_rounds_kernel", achieved=None if hbm is None else round(hbm, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                     frac=None if hbm is None else round(hbm / HBM_PEAK_GBS, 5), traffic=None, ms_per_volume=round(mws_ms, 3),
+                                     note="88 B/voxel algorithmic; round-latency bound (dependency-ordered union-find), see --workload segment"))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def cpu_baseline_aux(workload, size):
     import numpy as np
     cores, cpu = host_cpu()
@@ -473,6 +566,8 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if a.workload == "config5":
+        return main_config5(a, rank, local, world, dev)
     if a.workload in ("predict", "segment"):
         return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)

@@ -172,3 +172,39 @@ def test_predict_real_geometry_196_to_104_vs_cpu_oracle():
                     assert float(np.abs(b - want).max()) <= 5e-2 and np.sqrt(((b - want) ** 2).sum() / (want ** 2).sum()) <= 1.5e-2   # bf16: max over 30 M values (measured 3.8-4.2e-2)
     assert (dests[0][:, :46] == 0).all() and (dests[0][:, 254:] == 0).all()  # nothing written outside the write ROIs
     print(f"predict 196->104 x 8 blocks: worst |diff| vs fp32 CPU oracle {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_config5_chain_predict_then_segment_in_hbm():
+    """BASELINE config 5's chain on one GPU (raygun_amd.pipeline.predict_and_segment): 300^3 uint8 volume -> 8 blocks of 196^3 -> 104^3
+    through MTLSDModel(num_affs = 20) (config U, f16 storage), uint8 affinities left in HBM -> rg_mws_prepare -> mutex watershed.
+    Against the CPU chain: (1) the first block's uint8 affinities equal the fp32 CPU oracle's (worker.py:133-144 arithmetic) to +-1
+    grey level; (2) the labels equal numpy prepare + oracle/mws.c run on the SAME predicted affinities, bit for bit."""
+    from oracle import mws as OM, torch_ref as O
+    from raygun_amd import pipeline
+    from raygun_amd.torch.models import MTLSDModel
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    model = MTLSDModel(num_affs=20)
+    sd = synth.fill_state_dict(model.state_dict(), 31)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    z, y, x = np.meshgrid(*[np.arange(300, dtype=np.float32)] * 3, indexing="ij")
+    vol = (((np.abs(np.sin(z / 9.1 + 1) * np.sin(y / 11.3) * np.sin(x / 8.7 + 1)) > 0.2) * 140 + 40) + synth.uniform((300,) * 3, 32, 0, 60)).astype(np.uint8)
+    labels, info = pipeline.predict_and_segment(model, torch.from_numpy(vol).to(dev))
+    affs8 = info["affinities"].cpu().numpy()
+    assert info["blocks"] == 8 and affs8.shape == (20, 300, 300, 300) and affs8.dtype == np.uint8 and labels.shape == (300, 300, 300)
+    assert (affs8[:, :46] == 0).all() and affs8[:, 46:254, 46:254, 46:254].any()
+    # (1) block (46, 46, 46) against the fp32 CPU oracle
+    ref = O.MTLSDModel(num_affs=20); ref.load_state_dict(sd); ref.eval()
+    with torch.no_grad():
+        ra = ref(torch.from_numpy(vol[:196, :196, :196].astype(np.float32) / 255)[None, None])[0][0].numpy()
+    r8 = np.clip(ra * 255, 0, 255).astype(np.uint8)
+    d = np.abs(affs8[:, 46:150, 46:150, 46:150].astype(np.int16) - r8.astype(np.int16))
+    assert d.max() <= 1 and (d > 0).mean() < 0.08, (int(d.max()), float((d > 0).mean()))   # (f16 storage: ~1e-3 relative = 0.13 grey levels at 0.5)
+    # (2) the segmentation half on the predicted affinities
+    a = affs8.astype(np.float32) * np.float32(1.0 / 255.0)
+    ww, m = OM.prepare(a, 3, 0.5, 1.0)
+    want = OM.compute_mws_segmentation(ww, OM.neighborhood(8).astype(np.int32), 3, (10, 10, 10), m)
+    got = labels.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got, want) and got.max() > 1
