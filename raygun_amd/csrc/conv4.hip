@@ -354,6 +354,10 @@ __global__ __launch_bounds__(256) void igemm4_combine_kernel(Igemm4Args a) {
     *(bf16x4*)(yrow + c) = o;
   }
 }
+void rg_launch_igemm4_combine(const Igemm4Args& a, hipStream_t st) {
+  long blocks = (a.M * (a.cout_lanes >> 2) + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(igemm4_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
 // Split count for a grid of `tiles` workgroups on `slots` co-resident ones: split K when at most half the slots are used and
 // the K range is long enough (>= 4 units per split); never beyond what the caller's workspace holds
 static int ig4_ksplit(long tiles, long slots, int kunits) {
@@ -424,8 +428,8 @@ bool rg_igemm_thin_ok(const CL5& X, const rg_conv_params* p);
 int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
 int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
-bool rg_igemm5_ok(const Igemm4Args& a, bool flat);
-int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st);
+bool rg_igemm5_ok(const Igemm4Args& a, bool flat, size_t ws_bytes);
+int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_t ws_bytes);
 struct Igemm4Batch { int n; long xs, ws, ys; };
 static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                              void* workspace, size_t ws_bytes, const Igemm4Batch* bt);
@@ -467,7 +471,7 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
-  if (rg_igemm5_ok(a, flat != 0)) return rg_launch_igemm5(a, check, st);   // 256 x 288 tiles, both operands through LDS by LDS-DMA (gemm5.hip)
+  if (rg_igemm5_ok(a, flat != 0, ws_bytes)) return rg_launch_igemm5(a, check, st, (float*)workspace, ws_bytes);   // 256 x 288 / 256 tiles, both operands through LDS by LDS-DMA (gemm5.hip)
   if (flat && rg_halo16_ok(X, Y, p) && !rg_opt(RG_OPT_NO_HALO)) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
   if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !rg_opt(RG_OPT_NO_THIN)) return rg_launch_igemm_thin(a, check, st);
   const int nf = a.wrows / 16;

@@ -28,8 +28,7 @@
 typedef int g5_i32x4 __attribute__((ext_vector_type(4)));
 
 #define G5_BM 256
-#define G5_BN 288
-#define G5_BROWS 320                       // B rows staged per tile (5 DMA instructions of 64 rows; rows 288..319 are never fetched or read)
+#define G5_BROWS 320                       // B rows a stage holds (FN = 9: 288 used, 5 DMA instructions; FN = 8: 256 used, 4 instructions)
 #define G5_STAGE ((G5_BM + G5_BROWS) * 128) // bytes per stage
 #define G5_OOB 0x80000000u
 
@@ -55,8 +54,11 @@ __device__ __forceinline__ void g5for(F&& f) { g5_impl(f, std::make_integer_sequ
 // K-tile is one 64-channel chunk of one tap (chunk outer, tap inner: consecutive tiles read neighbouring voxels); the tap's byte
 // offset is added to each of the thread's 4 row offsets, rows / taps / channel lanes outside the tensor become out-of-range offsets
 // (zeros).  rg_gemm_batched's problems are the 1x1x1-tap case with a batch index in the grid.
-template <bool CHECK>
+// FN = 16-column fragments per wave: 9 (144-column halves, 288-column tiles: the U-Net's 432 / 2592 / 3456-channel layers) or 8 (128-column
+// halves, 256-column tiles: the CycleGAN's 256-channel ResNet blocks).
+template <bool CHECK, int FN>
 __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
+  constexpr int G5_BN = 2 * FN * 16, NB = (G5_BN + 63) / 64;   // columns per tile, B DMA instructions per thread and K-tile
   extern __shared__ __attribute__((aligned(128))) unsigned char g5_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,18 +139,18 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   const int fr = lane & 15, fg = lane >> 4;
   const unsigned flane = fr * 128 + ((fg ^ (fr >> 1)) << 4);
   const unsigned fa0 = lds0 + wm * (64 * 128) + flane;                        // A fragments of this wave, stage 0, k-half 0
-  const unsigned fb0 = lds0 + G5_BM * 128 + wn * (144 * 128) + flane;         // B fragments
+  const unsigned fb0 = lds0 + G5_BM * 128 + wn * (FN * 16 * 128) + flane;     // B fragments
 
-  f32x4 acc[4][9];
+  f32x4 acc[4][FN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: A(0), B(0) -> stage 0, A(1) -> stage 1 (stays in flight)
   const bool two = nk > 1;
   prep_a(); dma_a(0, C0{}); dma_a(0, C1{}); dma_a(0, C2{}); dma_a(0, C3{});
-  prep_b(); dma_b(0, C0{}); dma_b(0, C1{}); dma_b(0, C2{}); dma_b(0, C3{}); dma_b(0, C4{});
+  prep_b(); dma_b(0, C0{}); dma_b(0, C1{}); dma_b(0, C2{}); dma_b(0, C3{}); if constexpr (NB > 4) dma_b(0, C4{});
   if (two) {
     prep_a(); dma_a(1, C0{}); dma_a(1, C1{}); dma_a(1, C2{}); dma_a(1, C3{});
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -172,22 +174,24 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
     const unsigned sa = fa0 + stage * G5_STAGE, sb = fb0 + stage * G5_STAGE;
     g5for<4>([&](auto P) {
       constexpr int p = decltype(P)::value, h = p & 1, jg = p >> 1;
-      constexpr int J0 = jg ? 5 : 0, NJ = jg ? 4 : 5;
+      constexpr int J0 = jg ? (FN + 1) / 2 : 0, NJ = jg ? FN / 2 : (FN + 1) / 2;
       // ---- read segment
       __builtin_amdgcn_sched_barrier(0);
       const unsigned aa = sa ^ (h * 64), bb = sb ^ (h * 64);
       if constexpr (jg == 0) g5for<4>([&](auto I) { g5_ldr<decltype(I)::value * 2048>(af[h * 4 + decltype(I)::value], aa); });
       g5for<NJ>([&](auto J) { g5_ldr<(J0 + decltype(J)::value) * 2048>(bf[decltype(J)::value], bb); });
       if constexpr (p == 0) { if (more1) { prep_b(); dma_b(stage ^ 1, C0{}); dma_b(stage ^ 1, C1{}); dma_b(stage ^ 1, C2{}); } }
-      if constexpr (p == 1) { if (more1) { dma_b(stage ^ 1, C3{}); dma_b(stage ^ 1, C4{}); } }
+      if constexpr (p == 1) { if (more1) { dma_b(stage ^ 1, C3{}); if constexpr (NB > 4) dma_b(stage ^ 1, C4{}); } }
       if constexpr (p == 2) { if (more2) { prep_a(); dma_a(stage, C0{}); dma_a(stage, C1{}); } }
       if constexpr (p == 3) {
         if (more2) { dma_a(stage, C2{}); dma_a(stage, C3{}); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       // every fragment read of this phase has returned (names the registers: the MFMAs below depend on this statement)
-      if constexpr (jg == 0)
+      if constexpr (jg == 0 && NJ == 5)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[h * 4]), "+v"(af[h * 4 + 1]), "+v"(af[h * 4 + 2]), "+v"(af[h * 4 + 3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]) :: "memory");
+      else if constexpr (jg == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[h * 4]), "+v"(af[h * 4 + 1]), "+v"(af[h * 4 + 2]), "+v"(af[h * 4 + 3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) :: "memory");
       else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]) :: "memory");
       __builtin_amdgcn_s_barrier();
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
       if (m >= a.M) continue;
       float* prow = a.part + ((long)split * a.M + m) * a.cout_lanes;
 #pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const int c = n0 + wn * 144 + j * 16 + fg * 4;
+      for (int j = 0; j < FN; ++j) {
+        const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
         if (c < a.cout_lanes) *(f32x4*)(prow + c) = acc[i][j];
       }
     }
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
     bf16_t* yrow = ybase + t * a.ysn + (long)(rd_ * a.os[0] + a.oo[0]) * a.ysd + (long)(rh_ * a.os[1] + a.oo[1]) * a.ysh +
                    (long)(rw_ * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int c = n0 + wn * 144 + j * 16 + fg * 4;
+    for (int j = 0; j < FN; ++j) {
+      const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
       if (c >= a.cout_lanes) continue;
       bf16x4 o;
 #pragma unroll
@@ -250,36 +254,65 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   }
 }
 
-// Heuristic: the 288-column tile must be (nearly) full, the grid must give most CUs a workgroup (one 8-wave workgroup per CU), and K
-// must be long enough to amortise the two-tile prologue.  opt = rg_opt(RG_OPT_GEMM5): 0 heuristic, 1 wherever the tiling allows, -1 off.
-bool rg_igemm5_ok(const Igemm4Args& a, bool flat) {
+// Which igemm5 configuration serves this problem (0: none): FN = 9 for column counts in 144-column halves, FN = 8 for 128-column halves;
+// the tile must be (nearly) full, the grid must give most CUs a workgroup (ONE 8-wave workgroup per CU) — small grids with a long K are
+// cut into up to 8 K-slices whose fp32 partial tiles the caller's workspace holds ([slice][row][column], summed by igemm4's combine
+// kernel) — and K must be long enough to amortise the two-tile prologue.  opt = rg_opt(RG_OPT_GEMM5): 0 heuristic, 1 wherever the
+// tiling allows, 2 also the 432-column layers (one of whose two column tiles is half empty), -1 off.
+struct G5Plan { int fn; int ksplit; };
+static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size_t ws_bytes, int cout_lanes) {
+  G5Plan pl = {0, 1};
   const int opt = rg_opt(RG_OPT_GEMM5);
-  if (opt < 0 || flat || (a.wrows % 16) || a.cout_lanes < 8) return false;
-  const int nf = a.wrows / 16;
-  if (nf % 9) return false;                     // columns in 144-column halves
-  if (opt == 1) return true;
-  const long tiles_m = (a.M + G5_BM - 1) / G5_BM, tiles_n = (a.wrows + G5_BN - 1) / G5_BN;
-  const long tiles = tiles_m * tiles_n * a.nbatch;
-  const double fill_n = (double)a.wrows / (double)(tiles_n * G5_BN);
-  const int kunits = (a.cink >> 6) * a.TD * a.TH * a.TW;
-  // whole rounds of 256 workgroups: the last round's fill decides what a coarse tile costs
-  const double rounds = (double)tiles / 256.0, fill_r = rounds / (double)(long)(rounds + 0.999999);
-  const double fmin = opt == 2 ? 0.70 : 0.88;   // (2: also the 432-column layers, one of whose two column tiles is half empty — A/B switch)
-  return fill_n >= fmin && kunits >= 8 && tiles >= 150 && fill_r >= 0.70;
+  if (opt < 0 || flat || (wrows % 16) || cout_lanes < 8) return pl;
+  const int nf = wrows / 16;
+  const int fn = nf % 9 == 0 ? 9 : (nf % 8 == 0 ? 8 : 0);
+  if (!fn) return pl;
+  const int bn = 2 * fn * 16;
+  const long tiles_m = (M + G5_BM - 1) / G5_BM, tiles_n = (wrows + bn - 1) / bn;
+  const long tiles = tiles_m * tiles_n * nbatch;
+  if (opt == 1) { pl.fn = fn; return pl; }
+  const double fill_n = (double)wrows / (double)(tiles_n * bn);
+  if (fill_n < (opt == 2 ? 0.70 : 0.88) || kunits < 8) return pl;
+  auto round_fill = [](long t) { const double r = (double)t / 256.0; return r / (double)(long)(r + 0.999999); };
+  if (tiles >= 150 && round_fill(tiles) >= 0.70) { pl.fn = fn; return pl; }
+  if (nbatch == 1 && tiles < 150 && kunits >= 32 && (cout_lanes & 3) == 0) {   // split K: whole rounds of one workgroup per CU
+    long ks = 256 / tiles; if (ks > 8) ks = 8; if (ks > kunits / 16) ks = kunits / 16;
+    if (ks >= 2 && tiles * ks >= 150 && (size_t)ks * M * cout_lanes * 4 <= ws_bytes) { pl.fn = fn; pl.ksplit = (int)ks; }
+  }
+  return pl;
 }
+bool rg_igemm5_ok(const Igemm4Args& a, bool flat, size_t ws_bytes) {
+  return g5_plan(a.M, a.wrows, (a.cink >> 6) * a.TD * a.TH * a.TW, a.nbatch, flat, ws_bytes, a.cout_lanes).fn != 0;
+}
+// the same decision from the tensor views (conv.hip routes 128-channel-tile layers to igemm3 unless igemm5 takes them)
+bool rg_igemm5_wanted(const CL5& X, const CL5& Y, const rg_conv_params* p, size_t ws_bytes) {
+  const long M = (long)X.N * p->R[0] * p->R[1] * p->R[2];
+  return g5_plan(M, round_up(p->cout, 16), (round_up(X.C, 64) >> 6) * p->T[0] * p->T[1] * p->T[2], 1, false, ws_bytes, Y.lanes).fn != 0;
+}
+void rg_launch_igemm4_combine(const Igemm4Args& a, hipStream_t st);   // conv4.hip: y = act(sum of the K-slices' partial tiles + bias)
 
-int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st) {
+int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_t ws_bytes) {
+  const G5Plan pl = g5_plan(a.M, a.wrows, (a.cink >> 6) * a.TD * a.TH * a.TW, a.nbatch, false, ws_bytes, a.cout_lanes);
+  const int bn = 2 * pl.fn * 16;
   a.tiles_m = (int)((a.M + G5_BM - 1) / G5_BM);
-  a.tiles_n = (a.wrows + G5_BN - 1) / G5_BN;
-  a.ksplit = 1; a.part = nullptr;
+  a.tiles_n = (a.wrows + bn - 1) / bn;
+  a.ksplit = pl.ksplit; a.part = pl.ksplit > 1 ? ws : nullptr;
   static rg_device_latch attr;
   rg_once_per_device(&attr, [] {
-    hipFuncSetAttribute((const void*)igemm5_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
   });
-  rg_set_kernel_name("igemm5_kernel<%d>", (int)check);
-  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.nbatch));
-  if (check) hipLaunchKernelGGL(igemm5_kernel<true>, grid, dim3(512), 2 * G5_STAGE, st, a);
-  else hipLaunchKernelGGL(igemm5_kernel<false>, grid, dim3(512), 2 * G5_STAGE, st, a);
+  rg_set_kernel_name("igemm5_kernel<%d,%d>%s", (int)check, pl.fn, pl.ksplit > 1 ? "+splitK" : "");
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * a.nbatch));
+  if (pl.fn == 9) {
+    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    else hipLaunchKernelGGL((igemm5_kernel<false, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  } else {
+    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  }
+  if (a.ksplit > 1) rg_launch_igemm4_combine(a, st);
   return RG_OK;
 }

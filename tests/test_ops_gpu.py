@@ -679,6 +679,8 @@ def test_winograd_operands_follow_the_optimizer(monkeypatch):
     (432, 432, (8, 8, 9), 3, 1, 0, "none", 1),         # the U-Net's 432-channel layers: 7 chunks, 1.5 column tiles
     (128, 576, (10, 10, 10), 2, 1, 0, "relu", 1),      # 2^3 taps (the sub-pixel layers)
     (64, 288, (13, 12, 14), 3, 2, 1, "sigmoid", 1),    # strided rows
+    (128, 256, (12, 10, 11), 3, 1, 0, "relu", 1),      # FN = 8: 256-column tiles (the CycleGAN's ResNet blocks)
+    (256, 512, (9, 9, 10), 3, 1, 1, "leaky", 1),       # FN = 8, two column tiles, zero padding
 ])
 def test_igemm5_lds_dma_conv_forward_and_backward_data(cin, cout, sp, k, stride, pad, act, n):
     """gemm5.hip igemm5_kernel (256 x 288 tiles, both operands through LDS by LDS-DMA, staggered wave groups) forced on for
@@ -757,3 +759,23 @@ def test_wgrad_kwd_lds_dma_weight_gradient(cin, cout, sp, k, pad, n):
             assert relerr(gw, gwr) <= TOL, (opt, relerr(gw, gwr))
             outs[opt] = gw.float().cpu()
     assert relerr(outs[1], outs[0]) <= 2 ** -9
+
+
+@pytest.mark.gpu
+def test_igemm5_split_k_small_grid():
+    """igemm5 with K-slices (the 256 -> 256 ResNet-block convolution of the CycleGAN at 32^3: 128 row tiles x 1 column tile, K = 108
+    tiles -> 2 slices, fp32 partial tiles through the workspace, igemm4's combine kernel adds bias + activation): forward and
+    backward-data against torch fp32 on the CPU; the heuristic (RG_GEMM5 = 0) must pick the split by itself."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((1, 256, 34, 34, 34), 101); w0 = rnd((256, 256, 3, 3, 3), 102, -0.02, 0.02); b0 = rnd((256,), 103)
+    xr = x0.clone().requires_grad_()
+    yr = torch.relu(F.conv3d(xr, w0, b0))
+    go = rnd(tuple(yr.shape), 104)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    xd = x0.clone().to(dev).requires_grad_()
+    y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, 0, "relu")
+    name = _lib.lib().rg_last_kernel_name().decode()
+    assert "igemm5" in name and "splitK" in name, name
+    (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+    assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL, (relerr(y, yr), relerr(gx, gxr))
