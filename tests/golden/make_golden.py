@@ -425,7 +425,7 @@ def fx_cyclegan_ngf64():
     or the composed 64 -> 64 7^3 tail."""
     g3 = dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same")
     d3 = dict(input_nc=1, ngf=64, n_layers=3, kw=4)
-    fx_cyclegan("cyclegan_step_link_3d64_ngf64", 3, (1, 1, 64, 64, 64), g3, d3, "link", iters=2, g_lr=1e-4, d_lr=1e-4, sampled=True)
+    fx_cyclegan("cyclegan_step_link_3d64_ngf64", 3, (1, 1, 64, 64, 64), g3, d3, "link", iters=2, g_lr=1e-5, d_lr=1e-5, sampled=True)   # config 2's Adam lr (default_cycleGAN_conf.json:33-45)
 
 
 FIXTURES = {

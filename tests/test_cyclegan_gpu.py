@@ -206,7 +206,7 @@ def _system_ngf64(dev):
     cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
                gnet_kwargs=dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN, padding_type="same"),
                dnet_kwargs=dict(input_nc=1, ngf=64, n_layers=3, kw=4), loss_type="link", loss_kwargs={},
-               g_optim_kwargs=dict(betas=[0.5, 0.999], lr=1e-4), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=1e-4))
+               g_optim_kwargs=dict(betas=[0.5, 0.999], lr=1e-5), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=1e-5))
     with contextlib.redirect_stdout(sys.stderr):
         s = CycleGAN(cfg)
         s.setup_networks()

@@ -130,7 +130,7 @@ def test_cyclegan_3d_full_width_ngf64_first_iteration():
     ref = json.loads(str(fx["loss_dicts"]))[0]
     g3 = dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=IN3, padding_type="same")
     d3 = dict(input_nc=1, ngf=64, n_layers=3, kw=4)
-    model, loss, _ = O.build_cyclegan(3, g3, d3, split=False, g_lr=1e-4, d_lr=1e-4, betas=(0.5, 0.999), init=False)
+    model, loss, _ = O.build_cyclegan(3, g3, d3, split=False, g_lr=1e-5, d_lr=1e-5, betas=(0.5, 0.999), init=False)
     for i, net in enumerate([model.netG1, model.netG2, loss.netD1, loss.netD2]):
         net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i))
     A = T(synth.uniform((1, 1, 64, 64, 64), 90)); B = T(synth.uniform((1, 1, 64, 64, 64), 91))
