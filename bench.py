@@ -70,7 +70,7 @@ def build_unet(dev, size, seed):
 
     attached = []
 
-    def step(sync):
+    def step(sync, marks=None):
         if not attached:  # overlap the gradient all-reduce with the backward pass (no-op at world size 1)
             sync.attach(model.parameters()); attached.append(True)
         opt.zero_grad(set_to_none=True)
@@ -82,7 +82,12 @@ def build_unet(dev, size, seed):
         else:
             loss.backward()
         sync([p for p in model.parameters()])
-        opt.step()
+        if marks is not None:   # "fwd+bwd (+Adam reported separately)": one event pair around the optimiser call
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); opt.step(); e1.record()
+            marks.append((e0, e1))
+        else:
+            opt.step()
         return loss
 
     return step, dict(model="MTLSDModel(UNet ngf12 x6 3-level valid)+WeightedMSELoss_MTLSD+Adam", params=259146829)
@@ -504,8 +509,12 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
     barrier()
     ops.profile_start(select)
     t0 = time.perf_counter()
+    opt_marks = [] if workload == "unet" else None
     for _ in range(steps):
-        step(sync)
+        if opt_marks is not None:
+            step(sync, opt_marks)
+        else:
+            step(sync)
     t_enq = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind); close to dt = launch-bound
     barrier()
     dt = time.perf_counter() - t0
@@ -546,6 +555,8 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
                step_tflops=round(flop / (dt / steps) / 1e12, 2), executed_tflops=round(executed / (dt / steps) / 1e12, 2),
                step_frac_of_mfma_peak=round(flop / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 3),
+               **(dict(optimizer_ms=round(sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3),
+                       fwd_bwd_ms=round(ms - sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3)) if opt_marks else {}),
                executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                roofline=roofline, kernels=kernels)
     return res
