@@ -111,7 +111,10 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
   // the channels-last side (bf16, channel stride 1, 16-byte voxel granules) moves as ONE 16-byte access per thread; the dense
   // side stays one element per lane and channel (consecutive threads = consecutive voxels: coalesced)
   const bool dst_cl = dst.dtype == RG_ACT_DTYPE && dst.s[1] == 1 && (lanes & 7) == 0;
-  const bool src_cl = src.dtype == RG_ACT_DTYPE && src.s[1] == 1 && ((C + 7) / 8 * 8) <= lanes;
+  // (source: only WHOLE 8-channel groups are read as one vector — a view's voxel pitch need not cover zero-pad lanes, e.g. a
+  // channel slice of a wider tensor or a caller's tightly packed channels-last tensor: reading lanes >= C there runs into the
+  // next voxel and, at the last voxel, past the end of the allocation)
+  const bool src_cl = src.dtype == RG_ACT_DTYPE && src.s[1] == 1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long v = i % nvox; const int grp = (int)(i / nvox);
     long so, dof;
@@ -128,10 +131,10 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
       dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
     }
     float val[8];
-    if (src_cl && grp * 8 + 8 <= ((C + 7) / 8 * 8)) {
+    if (src_cl && grp * 8 + 8 <= C && (((unsigned long)((const bf16_t*)src.p + so + grp * 8)) & 15) == 0) {
       const bf16x8 raw = *(const bf16x8*)((const bf16_t*)src.p + so + grp * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) val[k] = grp * 8 + k < C ? bf2f((bf16_t)raw[k]) * scale + shift : 0.f;
+      for (int k = 0; k < 8; ++k) val[k] = bf2f((bf16_t)raw[k]) * scale + shift;
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {

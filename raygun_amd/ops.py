@@ -114,7 +114,7 @@ def _require_cuda(t, what):
 def desc(t):
     """rg_tensor descriptor of a torch tensor (rank <= 6)."""
     if _debug.ON:
-        _debug.check_view(t, lanes_of(t.shape[1]) if t.dim() == 5 and t.dtype in _KIND else None)
+        _debug.check_view(t, lanes_of(t.shape[1]) if is_cl(t) else None)   # (padded lanes exist only in the library's own layout)
     d = rg_tensor()
     d.ptr = t.data_ptr()
     d.dtype = _DT[t.dtype]
