@@ -170,7 +170,12 @@ def is_cl(t):
         return False
     if st[4] < lanes_of(c) or any(s % 8 for s in (st[2], st[3], st[4])) or (n > 1 and st[0] % 8):
         return False  # (the stride of a length-1 batch dimension is arbitrary: views renormalise it)
-    return t.data_ptr() % 16 == 0
+    if t.data_ptr() % 16:
+        return False
+    # kernels touch all lanes_of(c) lanes of every voxel: the last voxel's pad lanes must exist (torch's own as_strided backward
+    # hands back a view with this geometry over a storage that ends at the last LOGICAL element)
+    last = t.storage_offset() + (n - 1) * st[0] + (d - 1) * st[2] + (h - 1) * st[3] + (w - 1) * st[4] + lanes_of(c)
+    return t.numel() == 0 or last * t.element_size() <= t.untyped_storage().nbytes()
 
 
 def to_cl(t, scale=1.0, shift=0.0):

@@ -24,7 +24,8 @@ def test_bench_line_contract(workload, size):
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["vs_baseline"] is None and res["value"] > 0 and res["ms_per_step"] > 0
     assert "workload" in res["config"] and "model" not in res["config"]
     r = res["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    lo = -1 if os.environ.get("RAYGUN_AMD_DEBUG_BOUNDS") else 0   # (the debug switch waits after every call: rates at this size round to 0)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and lo < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the table holds every conv launch of one step; the dominant kernel was timed in both timed steps
     assert len(res["kernels"]) >= 5 and r["kernel"] == next(iter(res["kernels"]))
     assert r["launches_per_step"] == res["kernels"][r["kernel"]]["launches"]

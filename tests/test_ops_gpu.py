@@ -208,6 +208,33 @@ def test_add_and_activation():
     check(run_pair(lambda t: ops.activation(t, "sigmoid"), torch.sigmoid, [a], []), 8e-3)
 
 
+def test_to_cl_of_channel_slices_and_tight_channels_last_sources():
+    """`to_cl` of 16-bit views whose voxel pitch does NOT cover zero-pad lanes behind the logical channels — a channel slice of a wider tensor (what
+    torch.cat's backward hands on), a caller's tightly packed channels-last tensor: the values are those of the view, pad lanes come out zero, and the
+    source is never read beyond its channels (the kernel once read whole 16-byte groups there: behind the last voxel that is past the allocation —
+    DESIGN.md "the intermittent abort")."""
+    from raygun_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    wide = ops.to_cl(torch.randn(2, 24, 6, 5, 7, generator=g).to(dev))
+    cases = [wide[:, 12:24], wide[:, 4:23], wide[:, :12],
+             torch.randn(1, 4, 20, 20, 20, generator=g).to(dev).to(ops.storage_dtype()).contiguous(memory_format=torch.channels_last_3d),
+             torch.randn(2, 20, 3, 4, 5, generator=g).to(dev).to(ops.storage_dtype()).contiguous(memory_format=torch.channels_last_3d)[:, 3:]]
+    # the geometry of the library layout over a storage that ends at the last LOGICAL element (what torch's as_strided backward returns): not is_cl
+    short = torch.empty_strided((1, 1, 6, 6, 6), (1728, 1, 288, 48, 8), dtype=ops.storage_dtype(), device=dev).copy_(torch.randn(1, 1, 6, 6, 6, generator=g))
+    assert short.untyped_storage().nbytes() < 6 * 6 * 6 * 8 * 2 and not ops.is_cl(short) and ops.is_cl(wide) and ops.is_cl(wide[:, :12])
+    cases.append(short)
+    for v in cases:
+        out = ops.to_cl(v)
+        assert ops.is_cl(out) and out.shape == v.shape
+        assert torch.equal(out.float(), v.float())
+        c, lanes = v.shape[1], ops.lanes_of(v.shape[1])
+        if lanes > c and out.data_ptr() != v.data_ptr():   # a fresh tensor in the library layout has zero pad lanes (an aligned leading slice is used as is)
+            pad = torch.as_strided(out, (out.shape[0], lanes - c) + tuple(out.shape[2:]), out.stride(), out.storage_offset() + c)
+            assert not pad.any()
+        assert torch.equal(ops.from_cl(out), v.float())
+
+
 def test_losses():
     from raygun_amd import ops
     p = torch.from_numpy(synth.uniform((1, 3, 9, 9, 9), 81))
