@@ -37,8 +37,8 @@ CYC_FLOP_PER_STEP = 94.3e12    # SURVEY.md §8a train-step FLOP budget (link, id
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment", "config5"])
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
@@ -510,11 +510,14 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
     ops.profile_start(select)
     t0 = time.perf_counter()
     opt_marks = [] if workload == "unet" else None
-    for _ in range(steps):
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # per-step spread (reported beside the contract's mean)
+    step_ev[0].record()
+    for i in range(steps):
         if opt_marks is not None:
             step(sync, opt_marks)
         else:
             step(sync)
+        step_ev[i + 1].record()
     t_enq = time.perf_counter() - t0  # host time to enqueue the steps (the GPU runs behind); close to dt = launch-bound
     barrier()
     dt = time.perf_counter() - t0
@@ -555,6 +558,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
                step_tflops=round(flop / (dt / steps) / 1e12, 2), executed_tflops=round(executed / (dt / steps) / 1e12, 2),
                step_frac_of_mfma_peak=round(flop / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 3),
+               step_ms_each=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)],
                **(dict(optimizer_ms=round(sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3),
                        fwd_bwd_ms=round(ms - sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3)) if opt_marks else {}),
                executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),

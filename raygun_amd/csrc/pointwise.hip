@@ -778,44 +778,82 @@ extern "C" int rg_add_pad(const rg_tensor* a, const rg_tensor* b, const rg_tenso
 //   spread: y[n,d,h,w][kh*KW+kw] = x[n,d,h + s*kh, w + s*kw][0]   (0 outside x)
 //   sum   : y[n,d,h,w][0] = bias + sum_{kh,kw} x[n,d,h + s*kh, w + s*kw][kh*KW+kw]   (terms outside x dropped)
 // s = +1: im2col over (h,w) / the gather that finishes a conv;  s = -1: their adjoints.
-__global__ void diag_spread_kernel(CL5 x, CL5 y, int KH, int KW, int sgn) {
-  const long nvox = (long)y.N * y.D * y.H * y.W;
-  const int ngrp = y.lanes / 8;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox * ngrp; i += (long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % ngrp); long t = i / ngrp;
-    const int w = (int)(t % y.W); t /= y.W; const int h = (int)(t % y.H); t /= y.H; const int d = (int)(t % y.D); const int n = (int)(t / y.D);
+// spread: one workgroup per (n, d, SP_TH x SP_TW output tile).  The (SP_TH+KH-1) x (SP_TW+KW-1) window of the one-channel side is staged
+// in LDS as plain 2-byte scalars (one strided global load each, instead of 8 per 16-byte output group: the thread-per-group gather ran
+// at 1.5 TB/s of output), then consecutive threads write consecutive 16-byte channel groups (voxel-major): fully coalesced stores.
+#define SP_TH 4
+#define SP_TW 64
+__global__ __launch_bounds__(256) void diag_spread_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, int tiles_w, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t stile[];   // [RH*RW] window, then [lanes] per-channel window offsets (int)
+  const int RW = SP_TW + KW - 1, RH = SP_TH + KH - 1, G8 = y.lanes / 8;
+  int* coff = (int*)(stile + ((RH * RW + 7) & ~7));
+  int b = blockIdx.x;
+  const int tw = b % tiles_w; b /= tiles_w; const int th = b % tiles_h; b /= tiles_h; const int d = b % y.D; const int n = b / y.D;
+  const int h0 = th * SP_TH, w0 = tw * SP_TW;
+  const int ih0 = sgn > 0 ? h0 : h0 - (KH - 1), iw0 = sgn > 0 ? w0 : w0 - (KW - 1);
+  for (int i = threadIdx.x; i < RH * RW; i += 256) {
+    const int r = i / RW, c = i - r * RW;
+    const int hh = ih0 + r, ww = iw0 + c;
+    bf16_t v = 0;
+    if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) v = x.p[n * x.sn + d * x.sd + hh * x.sh + ww * x.sw];
+    stile[i] = v;
+  }
+  if (threadIdx.x < y.lanes) {
+    const int c = threadIdx.x, kh = c / KW, kw = c - kh * KW;
+    coff[c] = c < KH * KW ? sgn * (kh * RW + kw) : (1 << 30);
+  }
+  __syncthreads();
+  const int nitem = SP_TH * SP_TW * G8;
+  for (int it = threadIdx.x; it < nitem; it += 256) {
+    const int v = it / G8, g = it - v * G8;
+    const int lh = v / SP_TW, lw = v - lh * SP_TW;
+    const int h = h0 + lh, w = w0 + lw;
+    if (h >= y.H || w >= y.W) continue;
+    const int base = (sgn > 0 ? lh : lh + KH - 1) * RW + (sgn > 0 ? lw : lw + KW - 1);
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int c = g * 8 + k, kh = c / KW, kw = c - kh * KW;
-      const int hh = h + sgn * kh, ww = w + sgn * kw;
-      bf16_t v = 0;
-      if (c < KH * KW && (unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) v = x.p[n * x.sn + d * x.sd + hh * x.sh + ww * x.sw];
-      o[k] = (short)v;
+      const int off = coff[g * 8 + k];
+      o[k] = off == (1 << 30) ? (short)0 : (short)stile[base + off];
     }
     *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + g * 8) = o;
   }
 }
-// One workgroup per (n, d, DS_TH x DS_TW output tile): the (DS_TH+KH-1) x (DS_TW+KW-1) input voxel records are staged in LDS
-// with coalesced 16-byte loads (a thread-per-output gather of 2-byte lanes from KH*KW different records ran at 1.2 ms for
-// the 49-channel 128x134x134 tail tensor), then every thread sums its KH*KW diagonal entries.  LDS voxel stride 72 lanes
-// (144 B): 16 consecutive voxels start in 16 different banks.
-#define DS_TH 4
+// sum: one workgroup per (n, d, TH x DS_TW output tile): the (TH+KH-1) x (DS_TW+KW-1) input voxel records are staged in LDS with
+// coalesced 16-byte loads — ALL of a thread's loads of a batch are issued before the first LDS store (one load per iteration, waited
+// for at once, was 21 serialised HBM latencies per workgroup: 0.6 TB/s) — then every thread sums its KH*KW diagonal entries.
+// LDS voxel stride lanes + 4 (120 B for 49 channels): the 32 voxels of an output row start in 32 different banks.
 #define DS_TW 32
-#define DS_LS 72
-__global__ __launch_bounds__(128) void diag_sum_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, const float* bias, int tiles_w, int tiles_h) {
+template <int TH>
+__global__ __launch_bounds__(TH * DS_TW) void diag_sum_kernel(CL5 x, CL5 y, int KH, int KW, int sgn, const float* bias, int tiles_w, int tiles_h) {
   extern __shared__ __attribute__((aligned(16))) bf16_t dtile[];
-  const int RW = DS_TW + KW - 1, RH = DS_TH + KH - 1, G8 = x.lanes / 8;
+  constexpr int NT = TH * DS_TW, U = 8;
+  const int RW = DS_TW + KW - 1, RH = TH + KH - 1, G8 = x.lanes / 8, LS = x.lanes + 4;
   int b = blockIdx.x;
   const int tw = b % tiles_w; b /= tiles_w; const int th = b % tiles_h; b /= tiles_h; const int d = b % y.D; const int n = b / y.D;
-  const int h0 = th * DS_TH, w0 = tw * DS_TW;
+  const int h0 = th * TH, w0 = tw * DS_TW;
   const int ih0 = sgn > 0 ? h0 : h0 - (KH - 1), iw0 = sgn > 0 ? w0 : w0 - (KW - 1);
-  for (int i = threadIdx.x; i < RH * RW * G8; i += blockDim.x) {
-    const int g = i % G8, v = i / G8, c = v % RW, r = v / RW;
-    const int hh = ih0 + r, ww = iw0 + c;
-    bf16x8 val = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) val = *(const bf16x8*)(x.p + n * x.sn + d * x.sd + hh * x.sh + ww * x.sw + g * 8);
-    *(bf16x8*)(dtile + (r * RW + c) * DS_LS + g * 8) = val;
+  const int total = RH * RW * G8;
+  const bf16_t* xb = x.p + n * x.sn + d * x.sd;
+  for (int base = 0; base < total; base += NT * U) {
+    bf16x8 val[U]; int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * NT + (int)threadIdx.x;
+      val[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; dst[u] = -1;
+      if (i < total) {
+        const int v = i / G8, g = i - v * G8, r = v / RW, c = v - r * RW;
+        const int hh = ih0 + r, ww = iw0 + c;
+        dst[u] = v * LS + g * 8;
+        if ((unsigned)hh < (unsigned)x.H && (unsigned)ww < (unsigned)x.W) val[u] = *(const bf16x8*)(xb + hh * x.sh + ww * x.sw + g * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) {   // (8-byte aligned: two 64-bit stores)
+        const uint2 lo = {((const unsigned*)&val[u])[0], ((const unsigned*)&val[u])[1]}, hi = {((const unsigned*)&val[u])[2], ((const unsigned*)&val[u])[3]};
+        *(uint2*)(dtile + dst[u]) = lo; *(uint2*)(dtile + dst[u] + 4) = hi;
+      }
   }
   __syncthreads();
   const int lh = threadIdx.x / DS_TW, lw = threadIdx.x % DS_TW;
@@ -823,8 +861,10 @@ __global__ __launch_bounds__(128) void diag_sum_kernel(CL5 x, CL5 y, int KH, int
   if (h >= y.H || w >= y.W) return;
   float acc = bias ? bias[0] : 0.f;
   const int rb = sgn > 0 ? lh : lh + KH - 1, cb = sgn > 0 ? lw : lw + KW - 1;
-  for (int kh = 0; kh < KH; ++kh)
-    for (int kw = 0; kw < KW; ++kw) acc += bf2f(dtile[((rb + sgn * kh) * RW + cb + sgn * kw) * DS_LS + kh * KW + kw]);
+  for (int kh = 0; kh < KH; ++kh) {
+    const bf16_t* row = dtile + ((rb + sgn * kh) * RW + cb) * LS + kh * KW;
+    for (int kw = 0; kw < KW; ++kw) acc += bf2f(row[sgn * kw * LS + kw]);
+  }
   bf16x8 o = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
   o[0] = (short)f2bf(acc);
   *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw) = o;
@@ -841,21 +881,30 @@ static int diag_check(const rg_tensor* one, const rg_tensor* many, CL5* O, CL5* 
 extern "C" int rg_diag_spread(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, rg_stream s) {
   CL5 X, Y; int rc;
   if ((rc = diag_check(x, y, &X, &Y, kh, kw, "diag_spread"))) return rc;
-  const long total = (long)Y.N * Y.D * Y.H * Y.W * (Y.lanes / 8);
-  hipLaunchKernelGGL(diag_spread_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1);
+  const int tiles_w = (Y.W + SP_TW - 1) / SP_TW, tiles_h = (Y.H + SP_TH - 1) / SP_TH;
+  const size_t win = (size_t)(SP_TH + kh - 1) * (SP_TW + kw - 1);
+  const size_t shm = ((win + 7) & ~(size_t)7) * 2 + (size_t)Y.lanes * 4;
+  if (shm > 64 * 1024 || Y.lanes > 256) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_spread: %dx%d taps need %zu bytes of LDS", kh, kw, shm);
+  const long nblk = (long)Y.N * Y.D * tiles_h * tiles_w;
+  if (nblk >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_spread: grid too large");
+  if (nblk == 0) return RG_OK;
+  hipLaunchKernelGGL(diag_spread_kernel, dim3((unsigned)nblk), dim3(256), shm, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, tiles_w, tiles_h);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
 extern "C" int rg_diag_sum(const rg_tensor* x, const rg_tensor* y, int kh, int kw, int sign, const float* bias, rg_stream s) {
   CL5 X, Y; int rc;
   if ((rc = diag_check(y, x, &Y, &X, kh, kw, "diag_sum"))) return rc;
-  if (X.lanes > DS_LS) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: more than %d channel lanes", DS_LS);
-  const int tiles_w = (Y.W + DS_TW - 1) / DS_TW, tiles_h = (Y.H + DS_TH - 1) / DS_TH;
-  const size_t shm = (size_t)(DS_TH + kh - 1) * (DS_TW + kw - 1) * DS_LS * 2;
-  if (shm > 64 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: %dx%d taps need %zu bytes of LDS", kh, kw, shm);
+  const size_t per_row = (size_t)(DS_TW + kw - 1) * (X.lanes + 4) * 2;
+  const int TH = (8 + kh - 1) * per_row <= 64 * 1024 ? 8 : 4;
+  const size_t shm = (size_t)(TH + kh - 1) * per_row;
+  if (shm > 64 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: %dx%d taps of %d lanes need %zu bytes of LDS", kh, kw, X.lanes, shm);
+  const int tiles_w = (Y.W + DS_TW - 1) / DS_TW, tiles_h = (Y.H + TH - 1) / TH;
   const long nblk = (long)Y.N * Y.D * tiles_h * tiles_w;
   if (nblk >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "diag_sum: grid too large");
-  hipLaunchKernelGGL(diag_sum_kernel, dim3((unsigned)nblk), dim3(DS_TH * DS_TW), shm, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias, tiles_w, tiles_h);
+  if (nblk == 0) return RG_OK;
+  if (TH == 8) hipLaunchKernelGGL((diag_sum_kernel<8>), dim3((unsigned)nblk), dim3(8 * DS_TW), shm, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias, tiles_w, tiles_h);
+  else hipLaunchKernelGGL((diag_sum_kernel<4>), dim3((unsigned)nblk), dim3(4 * DS_TW), shm, (hipStream_t)s, X, Y, kh, kw, sign < 0 ? -1 : 1, bias, tiles_w, tiles_h);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
