@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment", "config5"])
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16"], help="unet workload: 16-bit storage type (f16 = IEEE half + dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="unet workload: do not also time the CycleGAN 128^3 step")
     ap.add_argument("--secondary-dp", action="store_true", help="with --gpus N > 1: time the CycleGAN step data-parallel as well (default: N = 1 only, "
@@ -51,7 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_unet(dev, size, seed):
+def build_unet(dev, size, seed, precision="bf16"):
     from raygun_amd import synth
     from raygun_amd.torch.models import MTLSDModel
     from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
@@ -69,28 +70,36 @@ def build_unet(dev, size, seed):
     w_a, w_l = torch.ones_like(gt_a), torch.ones_like(gt_l)
 
     attached = []
+    import contextlib
+    from raygun_amd import amp, ops
+    # f16 storage: IEEE-half activations / packed weights / activation gradients + dynamic loss scaling (raygun_amd/amp.py); the
+    # inf check and its 4-byte host read are part of the optimiser call, inside the timed step
+    scaler = amp.LossScaler() if precision == "f16" else None
 
     def step(sync, marks=None):
         if not attached:  # overlap the gradient all-reduce with the backward pass (no-op at world size 1)
             sync.attach(model.parameters()); attached.append(True)
         opt.zero_grad(set_to_none=True)
-        affs, lsds = model(raw)
-        loss = loss_fn(lsds, gt_l, w_l, affs, gt_a, w_a)
+        with (ops.precision("f16") if scaler is not None else contextlib.nullcontext()):
+            affs, lsds = model(raw)
+            loss = loss_fn(lsds, gt_l, w_l, affs, gt_a, w_a)
         ws = parallel.world_size()
+        out = scaler.scale(loss) if scaler is not None else loss
         if ws > 1 and sync.prescaled:   # mean over ranks = sum of gradients of loss / world: no division pass over 1 GB of gradients
-            loss.backward(torch.full_like(loss, 1.0 / ws))
+            out.backward(torch.full_like(loss, 1.0 / ws))
         else:
-            loss.backward()
+            out.backward()
         sync([p for p in model.parameters()])
+        do_step = (lambda: scaler.step(opt)) if scaler is not None else opt.step
         if marks is not None:   # "fwd+bwd (+Adam reported separately)": one event pair around the optimiser call
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); opt.step(); e1.record()
+            e0.record(); do_step(); e1.record()
             marks.append((e0, e1))
         else:
-            opt.step()
+            do_step()
         return loss
 
-    return step, dict(model="MTLSDModel(UNet ngf12 x6 3-level valid)+WeightedMSELoss_MTLSD+Adam", params=259146829)
+    return step, dict(model="MTLSDModel(UNet ngf12 x6 3-level valid)+WeightedMSELoss_MTLSD+Adam", params=259146829, scaler=scaler)
 
 
 def build_cyclegan(dev, size, seed):
@@ -480,14 +489,19 @@ def launch_ranks(a):
     return launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.rank_timeout)
 
 
-def run_train(a, workload, size, steps, warmup, rank, world, dev):
+def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf16"):
     """Time `steps` train steps of `workload` ('unet' | 'cyclegan') after `warmup` untimed ones: barrier + synchronize on both
     sides, MAX over ranks.  Returns the result dict (rank 0) or None."""
     import contextlib
     from raygun_amd import ops, parallel
     with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
-        step, info = (build_unet if workload == "unet" else build_cyclegan)(dev, size, seed=rank)
+        step, info = build_unet(dev, size, seed=rank, precision=precision) if workload == "unet" else build_cyclegan(dev, size, seed=rank)
     sync = parallel.GradSync(prescaled=(workload == "unet"))
+    # The interpreter's full (generation-2) garbage collection walks every object the imports created — ~70 ms on this image — and,
+    # landing in a timed step while the host is less than that ahead of the GPU, shows up as one 80-ms step (tools/step_trend.py).
+    # Long-lived objects go to the permanent generation, as raygun_amd's Trainer does before its loop.
+    import gc
+    gc.collect(); gc.freeze()
 
     def barrier():
         if world > 1:
@@ -545,13 +559,15 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev):
                         measured="HIP events around this kernel's launches inside the timed region; the `kernels` table is the fully instrumented last warm-up step")
     flop = (UNET_FLOP_PER_STEP if workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if workload == "unet" else 128)) ** 3
     executed = sum(v["flops"] for v in tab.values()) / tsteps  # what the conv / weight-gradient launches actually multiplied
-    res = dict(metric="Mvoxels/sec 3D UNet fwd+bwd 196^3 bf16" if workload == "unet" else "CycleGAN 128^3 train-step ms",
+    res = dict(metric=f"Mvoxels/sec 3D UNet fwd+bwd 196^3 {precision}" if workload == "unet" else "CycleGAN 128^3 train-step ms",
                value=round(size ** 3 * world / (dt / steps) / 1e6, 3) if workload == "unet" else round(ms, 3),
                unit="Mvoxels/s" if workload == "unet" else "ms/step", n_gpus=world, steps=steps, warmup=warmup,
-               ms_per_step=round(ms, 3), higher_is_better=workload == "unet", scaling="weak", vs_baseline=None, dtype="bf16",
+               ms_per_step=round(ms, 3), higher_is_better=workload == "unet", scaling="weak", vs_baseline=None, dtype=precision,
                data="synthetic",
                config=dict(workload=f"{workload} {size}^3 batch 1 per GPU, {info['model']}", params=info["params"],
-                           parallelism=f"dp{world}", precision="bf16 storage, fp32 accumulate, fp32 master weights + Adam state"),
+                           parallelism=f"dp{world}", precision=f"{precision} storage, fp32 accumulate, fp32 master weights + Adam state"
+                           + (", dynamic loss scaling" if precision == "f16" else "")),
+               **(dict(loss_scale=info["scaler"].scale_value, skipped_steps=info["scaler"].skipped) if info.get("scaler") is not None else {}),
                # algorithmic = the reference network's FLOPs / step time; executed = the FLOPs of the launches the
                # graph rewrites leave, summed over the step's conv + weight-gradient kernels / step time
                algorithmic_tflop_per_step=round(flop / 1e12, 3), executed_tflop_per_step=round(executed / 1e12, 3),
@@ -586,13 +602,27 @@ def main():
     if a.workload in ("predict", "segment"):
         return main_aux(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
-    res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev)
+    if a.precision == "f16" and a.workload != "unet":
+        raise SystemExit("bench.py: --precision f16 is the U-Net workload's (the CycleGAN losses own backward and step: bf16)")
+    res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev, precision=a.precision)
+    if a.workload == "unet" and a.precision == "bf16" and world == 1 and not a.no_secondary:
+        # the same step with IEEE-half storage and dynamic loss scaling: the mode whose trained precision meets north_star's 1e-3
+        # (DESIGN.md 4); reported beside the bf16 headline, never instead of it
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        h = run_train(a, "unet", size, max(3, a.steps // 2), max(3, a.warmup), rank, world, dev, precision="f16")
+        if res is not None and h is not None:
+            res["f16_storage"] = {k: h[k] for k in ("value", "unit", "ms_per_step", "fwd_bwd_ms", "optimizer_ms", "steps", "warmup", "dtype", "loss_scale",
+                                                     "skipped_steps") if k in h}
+            res["f16_storage"]["note"] = ("same network, step and sizes with f16 storage + dynamic loss scaling (raygun_amd/amp.py); optimizer_ms "
+                                          "includes the gradient inf check and its 4-byte host read")
+        del h
     if a.workload == "unet" and not a.no_secondary and (world == 1 or a.secondary_dp):
         # BASELINE's metric string has a second half — "CycleGAN 128^3 train-step ms" (config 2; with N > 1: config 4): timed in
         # the same run, after the U-Net's memory is released, and reported inside the same JSON line
         import gc
         gc.collect(); torch.cuda.empty_cache()
-        sec = run_train(a, "cyclegan", 128, max(3, a.steps // 2), 2, rank, world, dev)
+        sec = run_train(a, "cyclegan", 128, max(3, a.steps // 2), max(3, a.warmup), rank, world, dev)
         if res is not None and sec is not None:
             res["secondary"] = dict(metric=sec["metric"], value=sec["value"], unit=sec["unit"], ms_per_step=sec["ms_per_step"],
                                     steps=sec["steps"], warmup=sec["warmup"], higher_is_better=False, config=sec["config"],

@@ -227,6 +227,11 @@ int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, float grad_scale, void* packed, const rg_pack_params* pp, rg_stream s);
 
+/* ---- loss-scaled f16-storage training (no reference counterpart: the reference trains in fp32; torch.cuda.amp.GradScaler's
+ * "unscale and look for inf" step without the unscale pass — rg_adam_step takes 1/scale as grad_scale).
+ * *flag = 1.0f if any of the n values of g is inf or NaN; the flag is never cleared here (clear it once, check every gradient). */
+int rg_nonfinite_check(const float* g, int64_t n, float* flag, rg_stream s);
+
 /* ---- mutex watershed (affogato.segmentation.compute_mws_segmentation, called at segment.py:197-199).
  * affogato's Python wrapper (not vendored; signature as published: compute_mws_segmentation(weights, offsets,
  * number_of_attractive_channels, strides=None, randomize_strides=False, invert_repulsive_weights=True, bias_cut=0., mask=None,

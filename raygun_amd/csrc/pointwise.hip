@@ -1173,6 +1173,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[q] = pi; m[q] = mi; v[q] = vi;
   }
 }
+// any non-finite value in g -> *flag = 1 (never cleared here: one flag collects all the gradient tensors of a step).  Loss-scaled
+// f16-storage training (raygun_amd/amp.py): an activation gradient that left half's range reaches the weight gradients as inf / NaN.
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* g, long n, float* flag, int vec) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+  const long n4 = vec ? n / 4 : 0;
+  bool bad = false;
+  for (long i = tid; i < n4; i += nthr) {
+    const float4 v = ((const float4*)g)[i];
+    // (x - x) is 0 for every finite x and NaN for inf / NaN
+    bad |= ((v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w)) != 0.f;
+  }
+  for (long q = n4 * 4 + tid; q < n; q += nthr) bad |= (g[q] - g[q]) != 0.f;
+  if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;
+}
+extern "C" int rg_nonfinite_check(const float* g, int64_t n, float* flag, rg_stream s) {
+  if (!flag || (n > 0 && !g) || n < 0) RG_FAIL(RG_ERR_BAD_SHAPE, "nonfinite_check: bad arguments");
+  if (n == 0) return RG_OK;
+  const int vec = (((uintptr_t)g) & 15) == 0;
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(vec ? (n + 3) / 4 : n, 256, 4096)), dim3(256), 0, (hipStream_t)s, g, (long)n, flag, vec);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
 extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int32_t step, float grad_scale, rg_stream s) {
   return rg_adam_step_pack(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, nullptr, s);

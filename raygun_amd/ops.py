@@ -322,8 +322,8 @@ def pack_weights(w, swap, k0=(0, 0, 0), kstep=(1, 1, 1), ntap=None):
     _lib.check(_L().rg_pack_weights(C.c_void_p(wd.data_ptr()), C.c_void_p(out.data_ptr()), C.byref(p), _stream()),
                "rg_pack_weights")
     cache[key] = out
-    if src_cl and not swap and ntap is None and tuple(k0) == (0, 0, 0) and tuple(kstep) == (1, 1, 1) and red % 4 == 0 and len(key) == 4:
-        cache["fwd_pack"] = (out, p)  # FusedAdam refreshes this operand in its own pass (adam_step_)
+    if src_cl and not swap and ntap is None and tuple(k0) == (0, 0, 0) and tuple(kstep) == (1, 1, 1) and red % 4 == 0:
+        cache["fwd_pack" if len(key) == 4 else "fwd_pack_f16"] = (out, p, key)  # FusedAdam refreshes this operand in its own pass (adam_step_)
     return out
 
 
@@ -1363,6 +1363,14 @@ def weighted_mse(pred, target, weight):
 
 
 # ---------------------------------------------------------------------------------------------- Adam
+def nonfinite_check_(t, flag):
+    """flag (float32[1], device) <- 1 if the dense fp32 tensor `t` holds an inf / NaN (never cleared here)."""
+    if t.dtype != torch.float32 or not is_dense(t):
+        raise RuntimeError("raygun_amd.nonfinite_check_: dense fp32 tensor expected")
+    _lib.check(_lib.lib("bf16").rg_nonfinite_check(C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(flag.data_ptr()), _stream()),
+               "rg_nonfinite_check")
+
+
 def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place fused Adam on dense fp32 tensors of one layout (torch.optim.Adam semantics; optimizers/utils.py:4-9).
     If `p` is a channels-last conv weight whose forward operand is packed and current, the kernel rewrites that bf16
@@ -1370,9 +1378,9 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
     cache = getattr(p, "_rg_pack_cache", None)
     fwd = None
     if cache is not None and cache.get("ver") == (p._version, p.data_ptr()):
-        fwd = cache.get("fwd_pack")
+        fwd = cache.get("fwd_pack_f16") or cache.get("fwd_pack")   # (f16-storage training packs with the f16 library)
     if fwd is not None and os.environ.get("RAYGUN_AMD_ADAM_PACK", "1") != "0":
-        _lib.check(_lib.lib("bf16").rg_adam_step_pack(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+        _lib.check(_lib.lib(_KIND[fwd[0].dtype]).rg_adam_step_pack(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                                 C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                                 grad_scale, C.c_void_p(fwd[0].data_ptr()), C.byref(fwd[1]), _stream()),
                    "rg_adam_step_pack")

@@ -12,6 +12,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("raygun_amd.FusedAdam: amsgrad is not built")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
+        self.grad_scale = 1.0   # gradients are multiplied by this inside the kernel (amp.LossScaler sets 1 / loss scale around step())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,9 +44,9 @@ class FusedAdam(torch.optim.Optimizer):
                     if st[k].stride() != p.stride():  # e.g. a state dict loaded from a contiguous checkpoint
                         st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
                 fwd = ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
-                                     group["weight_decay"], int(st["step"]))
+                                     group["weight_decay"], int(st["step"]), float(self.grad_scale))
                 # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
                 torch.autograd.graph.increment_version(p)
                 if fwd is not None:  # the forward operand was refreshed in the same pass: it is current for the new version
-                    p._rg_pack_cache = {"ver": (p._version, p.data_ptr()), (0, (0, 0, 0), (1, 1, 1), None): fwd[0], "fwd_pack": fwd}
+                    p._rg_pack_cache = {"ver": (p._version, p.data_ptr()), fwd[2]: fwd[0], ("fwd_pack" if len(fwd[2]) == 4 else "fwd_pack_f16"): fwd}
         return loss

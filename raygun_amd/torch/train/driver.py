@@ -13,30 +13,41 @@ BaseSystem.py:118-121; PARITY UNPINNED beyond those two keys: the gunpowder fork
 `iteration` and, for the CycleGAN whose BaseDummyOptimizer is a parameter-less Module (state_dict() == {}), the wrapped
 optimisers' and schedulers' state under `optimizers` / `schedulers`, so a resumed run continues with its Adam moments.
 """
+import contextlib
 import inspect
 import os
 
 import torch
+
+from ... import ops
 
 
 def _names(fn):
     return [p for p in inspect.signature(fn).parameters if p not in ("self", "args", "kwargs")]
 
 
-def train_step(model, loss_fn, optimizer, batch, grad_sync=None):
-    """One iteration.  Returns (loss, outputs dict)."""
+def train_step(model, loss_fn, optimizer, batch, grad_sync=None, scaler=None):
+    """One iteration.  Returns (loss, outputs dict).  `scaler` (amp.LossScaler): f16 storage with dynamic loss scaling — the
+    config's "precision": "f16" — for systems whose loss leaves backward and step to the driver (MTLSD)."""
     if hasattr(optimizer, "zero_grad"):
         optimizer.zero_grad()
+    if scaler is not None and not isinstance(optimizer, torch.optim.Optimizer):
+        raise RuntimeError("raygun_amd.train_step: loss scaling needs a loss that leaves backward() and step() to the driver "
+                           "(the CycleGAN losses own both: train them in bf16)")
     in_names = _names(model.forward)
-    outs = model(**{k: batch[k] for k in in_names if k in batch})
-    outs = outs if isinstance(outs, (tuple, list)) else (outs,)
-    named = dict(zip(model.output_arrays, outs))
-    pool = {**batch, **named}
-    loss = loss_fn(*[pool[k] for k in _names(loss_fn.forward)])
-    loss.backward()  # a no-op for the CycleGAN losses, which own their backward+step (LinkCycleLoss.py:173)
+    with (ops.precision("f16") if scaler is not None else contextlib.nullcontext()):
+        outs = model(**{k: batch[k] for k in in_names if k in batch})
+        outs = outs if isinstance(outs, (tuple, list)) else (outs,)
+        named = dict(zip(model.output_arrays, outs))
+        pool = {**batch, **named}
+        loss = loss_fn(*[pool[k] for k in _names(loss_fn.forward)])
+    (scaler.scale(loss) if scaler is not None else loss).backward()  # a no-op for the CycleGAN losses, which own their backward+step (LinkCycleLoss.py:173)
     if grad_sync is not None and isinstance(optimizer, torch.optim.Optimizer):
         grad_sync([p for g in optimizer.param_groups for p in g["params"]])
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+    else:
+        optimizer.step()
     return loss, named
 
 
@@ -51,6 +62,13 @@ class Trainer:
     def __init__(self, system):
         self.system = system
         self.iteration = getattr(system, "iteration", 0) or 0
+        self.scaler = None
+        prec = str(getattr(system, "precision", "bf16") or "bf16").lower()
+        if prec in ("f16", "fp16", "half", "float16"):
+            from ... import amp
+            self.scaler = amp.LossScaler(**(getattr(system, "loss_scale_kwargs", None) or {}))
+        elif prec not in ("bf16", "bfloat16"):
+            raise ValueError(f"raygun_amd.Trainer: precision {prec!r} (expected \"bf16\" or \"f16\")")
 
     def train(self, iterations, batches=None):
         s = self.system
@@ -60,10 +78,14 @@ class Trainer:
             raise RuntimeError("raygun_amd.Trainer: no batch source (pass `batches=` or give the config `sources` / "
                                "\"synthetic_data\": true; the gunpowder data pipes are out of scope)")
         last = None
+        # a full garbage collection over everything the imports created costs ~70 ms of host time and can starve the GPU for one
+        # step: what exists now is long-lived, keep it out of the collector's way
+        import gc
+        gc.collect(); gc.freeze()
         for batch in batches:
             if self.iteration >= iterations:
                 break
-            loss, outs = train_step(s.model, s.loss, s.optimizer, batch, getattr(s, "grad_sync", None))
+            loss, outs = train_step(s.model, s.loss, s.optimizer, batch, getattr(s, "grad_sync", None), self.scaler)
             self.iteration += 1
             for obj in (s.model, s.loss):
                 if hasattr(obj, "update_status"):
@@ -82,6 +104,8 @@ class Trainer:
         os.makedirs(os.path.dirname(s.checkpoint_basename) or ".", exist_ok=True)
         path = f"{s.checkpoint_basename}_checkpoint_{self.iteration}"
         ck = {"model_state_dict": s.model.state_dict(), "optimizer_state_dict": s.optimizer.state_dict(), "iteration": self.iteration}
+        if self.scaler is not None:
+            ck["loss_scaler"] = self.scaler.state_dict()
         if not isinstance(s.optimizer, torch.optim.Optimizer):
             ck["optimizers"] = {k: o.state_dict() for k, o in _named_optimizers(s.optimizer).items()}
             ck["schedulers"] = {k: sch.state_dict() for k, sch in getattr(s.optimizer, "schedulers", {}).items()}
@@ -104,5 +128,7 @@ class Trainer:
             for k, sch in getattr(s.optimizer, "schedulers", {}).items():
                 if k in ck.get("schedulers", {}):
                     sch.load_state_dict(ck["schedulers"][k])
+        if self.scaler is not None and "loss_scaler" in ck:
+            self.scaler.load_state_dict(ck["loss_scaler"])
         self.iteration = int(ck.get("iteration", getattr(s, "iteration", 0) or 0))
         return ck

@@ -1,0 +1,125 @@
+"""f16-storage training with dynamic loss scaling (raygun_amd/amp.py): the inf check kernel, the scale policy, FusedAdam with 1/scale
+folded in, and the HEADLINE config's train step in f16 against the reference-generated fixture — the mode in which the trained
+precision meets north_star's "within 1e-3" (bf16, the benchmarked default, sits at 6.6e-3: DESIGN.md 4)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raygun_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+T = torch.from_numpy
+
+
+def l2rel(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def test_nonfinite_check_kernel():
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    flag = torch.zeros(1, device=dev)
+    for n in (1, 3, 4, 1000, 4099, 1 << 22):
+        g = torch.randn(n + 1, device=dev)[1:] if n == 4099 else torch.randn(n, device=dev)   # (one case not 16-byte aligned)
+        ops.nonfinite_check_(g, flag)
+        assert float(flag) == 0.0
+        for pos, bad in ((0, float("inf")), (n - 1, float("nan")), (n // 2, float("-inf"))):
+            h = g.clone(); h[pos] = bad
+            if n == 4099:
+                h = torch.cat([torch.zeros(1, device=dev), h])[1:]
+            flag.zero_(); ops.nonfinite_check_(h, flag)
+            assert float(flag) == 1.0, (n, pos, bad)
+        flag.zero_()
+    big = torch.full((1000,), 3.0e38, device=dev)   # large but finite
+    ops.nonfinite_check_(big, flag)
+    assert float(flag) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.nonfinite_check_(big.double(), flag)
+
+
+def test_fused_adam_with_folded_scale_equals_torch_adam_and_skips_on_overflow():
+    from raygun_amd import amp
+    from raygun_amd.torch.optimizers import FusedAdam
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 5, 3, 3, 3), (33,), (16, 8, 1, 1, 1)]
+    ref = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref, o_mine = torch.optim.Adam(ref, lr=1e-3), FusedAdam(mine, lr=1e-3)
+    sc = amp.LossScaler(init_scale=2.0 ** 10, growth_interval=3)
+    for it in range(4):
+        grads = [torch.randn(s, generator=g).to(dev) * 1e-3 for s in shapes]
+        for r, m, gr in zip(ref, mine, grads):
+            r.grad = gr.clone(); m.grad = gr * sc.scale_value          # what a backward through sc.scale(loss) leaves
+        o_ref.step()
+        assert sc.step(o_mine) is True
+        for r, m in zip(ref, mine):
+            assert torch.allclose(r, m, rtol=0, atol=2e-7), it
+    assert sc.scale_value == 2.0 ** 11 and sc.clean_steps == 1 and sc.skipped == 0   # doubled after 3 clean steps
+    before = [m.detach().clone() for m in mine]
+    steps_before = [float(o_mine.state[m]["step"]) for m in mine]
+    for m, s in zip(mine, shapes):
+        m.grad = torch.randn(s, generator=g).to(dev)
+    mine[1].grad[5] = float("inf")
+    assert sc.step(o_mine) is False
+    assert sc.scale_value == 2.0 ** 10 and sc.skipped == 1 and sc.clean_steps == 0
+    for m, b, st in zip(mine, before, steps_before):
+        assert torch.equal(m, b) and float(o_mine.state[m]["step"]) == st      # nothing moved, Adam's step count did not advance
+    assert o_mine.grad_scale == 1.0
+    d = sc.state_dict(); sc2 = amp.LossScaler(); sc2.load_state_dict(d)
+    assert sc2.state_dict() == d
+
+
+def test_mtlsd_196_f16_train_step_with_loss_scaling_vs_reference():
+    """The headline config (config U, 196^3 -> 104^3) trained one step in f16 storage with loss scaling, against the same
+    reference-generated fixture the bf16 test uses (tests/golden/mtlsd_196_sampled.npz): outputs within 1e-3 (north_star), loss and
+    gradients several times tighter than the bf16 policy allows, and the step is applied (no overflow at the initial scale)."""
+    from raygun_amd import amp, ops
+    from raygun_amd.torch.models import MTLSDModel
+    from raygun_amd.torch.losses import WeightedMSELoss_MTLSD
+    from raygun_amd.torch.optimizers import FusedAdam
+    fx = np.load(os.path.join(G, "mtlsd_196_sampled.npz"))
+    dev = torch.device("cuda")
+    m = MTLSDModel()
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 51))
+    m = m.to(dev)
+    opt = FusedAdam(m.parameters(), lr=0.5e-4)
+    sc = amp.LossScaler()
+    raw = T(synth.uniform((1, 1, 196, 196, 196), 52)).to(dev)
+    with ops.precision("f16"):
+        affs, lsds = m(raw)
+        gt_l = T(synth.uniform(tuple(lsds.shape), 53, 0, 1)).to(dev)
+        gt_a = T(synth.uniform(tuple(affs.shape), 54, 0, 1)).to(dev)
+        loss = WeightedMSELoss_MTLSD()(lsds, gt_l, torch.ones_like(lsds), affs, gt_a, torch.ones_like(affs))
+    sc.scale(loss).backward()
+    flat = torch.cat([affs.detach().reshape(-1), lsds.detach().reshape(-1)])
+    got = flat[torch.from_numpy(fx["out_idx"]).to(dev)].cpu().numpy()
+    res = {"out": l2rel(got, fx["out_val"]), "loss": abs(float(loss.detach()) - float(fx["loss"])) / float(fx["loss"])}
+    P = dict(m.named_parameters())
+    S = sc.scale_value
+    res["g_aff_w"] = l2rel(P["aff_head.conv_pass.0.weight"].grad / S, fx["g_aff_w"])
+    res["g_last_bias"] = l2rel(P["unet.r_conv.0.0.conv_pass.2.bias"].grad / S, fx["g_last_bias"])
+    big = P["unet.l_conv.3.conv_pass.2.weight"].grad.reshape(-1)[torch.from_numpy(fx["g_big_idx"]).to(dev)] / S
+    res["g_big"] = l2rel(big, fx["g_big_val"])
+    gs = json.loads(str(fx["grad_sums"]))
+    res["sum"] = max(abs(float(P[k].grad.double().sum()) / S - s1) / sabs for k, (s1, sabs) in gs.items())
+    res["abs"] = max(abs(float(P[k].grad.double().abs().sum()) / S - sabs) / sabs for k, (s1, sabs) in gs.items())
+    print("f16 train step vs reference:", {k: f"{v:.2e}" for k, v in res.items()})
+    assert res["out"] <= 1e-3
+    assert res["loss"] <= 2e-3
+    # measured 9.5e-4 / 5.0e-4 / 1.7e-3 / 7.3e-4 / 8.9e-4 (bf16 asserts 3e-2 / 4e-2 / 0.15 / 0.08 / 0.15 on the same quantities)
+    assert res["g_aff_w"] <= 3e-3 and res["g_last_bias"] <= 3e-3
+    assert res["g_big"] <= 6e-3
+    assert res["sum"] <= 4e-3 and res["abs"] <= 4e-3
+    w0 = P["aff_head.conv_pass.0.weight"].detach().clone()
+    assert sc.step(opt) is True and sc.skipped == 0
+    moved = (P["aff_head.conv_pass.0.weight"].detach() - w0).abs().max()
+    assert 0 < float(moved) <= 1.01 * 0.5e-4       # Adam's first step: lr * g / (|g| + eps)

@@ -1,5 +1,9 @@
 """Host-side decisions that need no GPU (run in the CPU suite)."""
 import os
+
+import pytest
+
+
 def test_winograd_gating_is_per_pass():
     """ops._wino_ok (host logic, no GPU): a pass takes the Winograd path when ITS reduction length reaches WINO_MIN_CHANNELS — config U's
     2592 -> 2592 level both ways, 432 -> 2592 only in the backward-data pass — and never for strides, paddings, other kernel sizes, the
@@ -26,3 +30,34 @@ def test_winograd_gating_is_per_pass():
         assert not ok(w_sq)
     finally:
         del os.environ["RAYGUN_AMD_WINOGRAD"]
+
+
+def test_loss_scaler_policy_and_trainer_precision_switch():
+    """amp.LossScaler's scale policy (torch.cuda.amp.GradScaler's: halve on overflow, double after `growth_interval` clean steps, the
+    optimizer untouched on a skipped step) with the device check stubbed out, and the Trainer's "precision" config switch."""
+    import types
+    from raygun_amd import amp
+    from raygun_amd.torch.train.driver import Trainer
+
+    class Opt:
+        param_groups = [{"params": []}]
+        grad_scale = 1.0
+        calls = []
+
+        def step(self):
+            self.calls.append(self.grad_scale)
+
+    sc = amp.LossScaler(init_scale=8.0, growth_interval=2, min_scale=1.0, max_scale=32.0)
+    seq = iter([False, False, True, False, False, False, False, True, True, True, True])
+    sc.found_inf = lambda params: next(seq)
+    o = Opt()
+    applied = [sc.step(o) for _ in range(11)]
+    assert applied == [True, True, False, True, True, True, True, False, False, False, False]
+    assert o.calls == [1 / 8, 1 / 8, 1 / 8, 1 / 8, 1 / 16, 1 / 16] and o.grad_scale == 1.0    # 8 -> 16 -> 8 -> 16 -> 32 ...
+    assert sc.scale_value == 2.0 and sc.skipped == 5                                          # ... -> 16 -> 8 -> 4 -> 2
+    with pytest.raises(RuntimeError):
+        sc.step(types.SimpleNamespace(param_groups=[], step=lambda: None))                    # no grad_scale: not FusedAdam
+    assert Trainer(types.SimpleNamespace(precision="f16", loss_scale_kwargs={"init_scale": 4.0})).scaler.scale_value == 4.0
+    assert Trainer(types.SimpleNamespace()).scaler is None and Trainer(types.SimpleNamespace(precision="bf16")).scaler is None
+    with pytest.raises(ValueError):
+        Trainer(types.SimpleNamespace(precision="fp8"))

@@ -6,7 +6,8 @@ from raygun_amd import ops
 wl = sys.argv[1] if len(sys.argv) > 1 else "cyclegan"
 dev = torch.device("cuda")
 step, info = (bench.build_unet if wl == "unet" else bench.build_cyclegan)(dev, 196 if wl == "unet" else 128, seed=0)
-sync = lambda params: None
+from raygun_amd import parallel
+sync = parallel.GradSync()
 for _ in range(2): step(sync)
 torch.cuda.synchronize()
 ops.profile_shapes = True
