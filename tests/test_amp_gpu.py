@@ -62,7 +62,7 @@ def test_fused_adam_with_folded_scale_equals_torch_adam_and_skips_on_overflow():
         o_ref.step()
         assert sc.step(o_mine) is True
         for r, m in zip(ref, mine):
-            assert torch.allclose(r, m, rtol=0, atol=2e-7), it
+            assert torch.allclose(r, m, rtol=1e-6, atol=1e-6), it
     assert sc.scale_value == 2.0 ** 11 and sc.clean_steps == 1 and sc.skipped == 0   # doubled after 3 clean steps
     before = [m.detach().clone() for m in mine]
     steps_before = [float(o_mine.state[m]["step"]) for m in mine]
