@@ -124,8 +124,9 @@ class GradSync:
     >= 11.9 ms if a single ring binds it to one link; CycleGAN generators 0.2 GB + discriminators 0.09 GB: 0.3 / 2.3 ms and
     0.15 / 1.0 ms.  Against a 29-ms U-Net step the exchange hides behind the backward pass in either case."""
 
-    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, small_bytes=SMALL_BYTES, prescaled=False):
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, small_bytes=SMALL_BYTES, prescaled=False, force=False):
         self.group = group
+        self.force = bool(force)   # run the collectives in a one-rank group too (tests: the RCCL code path on a one-GPU box)
         # prescaled: the caller already scaled the loss (its backward seed) by 1 / world size, so the SUM is the mean and the pass
         # that divides a gigabyte of gradients afterwards (0.45 ms per U-Net step) is not needed
         self.prescaled = bool(prescaled)
@@ -136,7 +137,7 @@ class GradSync:
         self.stats = dict(large=0, buckets=0, small=0)   # collectives issued by the last call
 
     def attach(self, params):
-        if world_size() == 1:
+        if world_size() == 1 and not self.force:
             return self
         for p in params:
             if p.requires_grad:
@@ -174,7 +175,7 @@ class GradSync:
 
     def __call__(self, params):
         ws = world_size()
-        if ws == 1:
+        if ws == 1 and not self.force:
             return
         params = [p for p in params if p.grad is not None]
         started = [self._pending.pop(id(p)) for p in params if id(p) in self._pending]

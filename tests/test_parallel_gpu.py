@@ -33,3 +33,32 @@ def test_segment_slabs_rccl_two_ranks_bit_exact():
     labs = run_ranks(_seg_rank, 2, shape, parts, None, (2, 2, 2), True, backend="nccl")
     w, mask = _slab_case(shape, 11, True)
     assert (np.concatenate(labs, 0) == O.slab_mws(w, NB8, 3, (2, 2, 2), mask, parts)).all()
+
+
+def _rccl_world1(rank, world):
+    """A ONE-rank RCCL group on the one GPU of the box: communicator set-up, asynchronous all-reduce handles started from autograd
+    hooks, flat buckets — the device-tensor code path the gloo twins cannot reach — with the sums of one rank as the known answer."""
+    import torch.distributed as dist
+    from raygun_amd import parallel
+    from tests.test_multirank_gpu import _mtlsd, _mtlsd_steps
+    assert world == 1 and not dist.is_initialized()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and not parallel._host_staged()
+    dev = torch.device("cuda", 0)
+    from raygun_amd import synth
+    raw = torch.from_numpy(synth.uniform((1, 1, 36, 36, 36), 9)).to(dev)
+    sync = parallel.GradSync(small_bytes=2048, force=True)
+    got = _mtlsd_steps(_mtlsd(dev), raw, 3, sync)
+    ref = _mtlsd_steps(_mtlsd(dev), raw, 3, None)
+    same = all(torch.equal(a, b) for a, b in zip(got, ref))
+    # the small exchanges of the sharded segmentation, on device tensors
+    t = torch.arange(5, device=dev)
+    gathered = parallel.all_gather_cat(t)
+    ints = parallel.all_gather_ints([3, 4])
+    return same, sync.stats, gathered.tolist(), [list(i) for i in ints]
+
+
+def test_rccl_one_rank_group_on_one_gpu():
+    same, stats, gathered, ints = run_ranks(_rccl_world1, 1, backend="nccl")[0]
+    assert same and stats["large"] > 0 and stats["buckets"] >= 1, stats     # sum over one rank / 1 == the plain run, bit for bit
+    assert gathered == [0, 1, 2, 3, 4] and ints == [[3, 4]]
