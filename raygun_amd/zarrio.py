@@ -9,7 +9,8 @@ laid down by hand from the spec.
 Codecs: none, zlib, gzip, bz2, lzma (python stdlib), and READING of Blosc frames — zarr's own default compressor — with the lz4 /
 lz4hc / zlib inner codecs and byte- or bit-shuffle (`blosc_decode`, restated from the published c-blosc 1.x frame layout and the
 LZ4 block format; the LZ4 stream is decoded by the library's host-side `rg_lz4_decompress_block`, or by a slow pure-Python twin
-when the library is not built; blosclz / zstd / snappy inner codecs raise).  New arrays are written with zlib.  PARITY UNPINNED
+when the library is not built; blosclz / zstd / snappy inner codecs raise) and WRITING of Blosc frames with the zlib inner codec
+(`blosc_encode`: arrays created by zarr / daisy with the default blosc compressor can be written into).  New arrays are written with zlib.  PARITY UNPINNED
 against numcodecs' Blosc as well: the tests decode frames laid down by hand from the format description.
 Filters are not supported.  N5 containers (the other format daisy.open_ds accepts) are READ through `N5Array`: attributes.json
 (dimensions / blockSize / dataType / compression, all in N5's fastest-axis-first order, reversed here), big-endian block files
@@ -131,12 +132,45 @@ def blosc_decode(buf):
     return bytes(out)
 
 
-def _no_blosc_write(b, cfg):
-    raise NotImplementedError("writing Blosc chunks is not supported: create the array with compressor zlib / gzip / none")
+def blosc_encode(raw, cfg):
+    """bytes -> one Blosc (c-blosc 1.x) frame any Blosc reader decodes: the inner codec is named by the FRAME's flags, not by the
+    array's metadata, so an array whose .zarray says blosc / lz4 (zarr's and daisy.prepare_ds's default) takes frames compressed with
+    the zlib inner codec (python's stdlib; codec id 3) — byte-shuffled when the element is wider than a byte and `shuffle` is not 0,
+    blocks not split (flag 0x10), a block that does not shrink stored as is (stream size == block size), an incompressible chunk as a
+    memcpy frame (flag 0x2).  `cfg`: the compressor dict (+ "_typesize" from the array's dtype; clevel -> zlib level)."""
+    raw = bytes(raw)
+    n = len(raw)
+    ts = int(cfg.get("_typesize", 1))
+    ts = ts if 1 <= ts <= 255 else 1
+    level = max(1, min(9, int(cfg.get("clevel", 5))))
+    shuffle = ts > 1 and int(cfg.get("shuffle", 1)) != 0
+    bs = int(cfg.get("blocksize", 0)) or (1 << 18)
+    bs = max(ts, bs // ts * ts)
+    if n >= (1 << 31) - 16 - 4 * ((n + bs - 1) // bs + 1):
+        raise ValueError("blosc: chunk too large for one frame")
+    nblocks = (n + bs - 1) // bs if n else 0
+    body, starts, pos = [], [], 16 + 4 * nblocks
+    for b in range(nblocks):
+        blk = raw[b * bs:(b + 1) * bs]
+        if shuffle:
+            a = np.frombuffer(blk, np.uint8)
+            nel = len(blk) // ts
+            blk = a[:nel * ts].reshape(nel, ts).T.tobytes() + bytes(a[nel * ts:])
+        c = zlib.compress(blk, level)
+        if len(c) >= len(blk):
+            c = blk                                   # stored stream: its size equals the block's
+        starts.append(pos)
+        body.append(len(c).to_bytes(4, "little") + c)
+        pos += 4 + len(c)
+    flags = (0x1 if shuffle else 0) | 0x10 | (3 << 5)
+    if pos >= n + 16:                                 # nothing gained: the stored form
+        return bytes([2, 1, flags | 0x2, ts]) + n.to_bytes(4, "little") + bs.to_bytes(4, "little") + (n + 16).to_bytes(4, "little") + raw
+    return (bytes([2, 1, flags, ts]) + n.to_bytes(4, "little") + bs.to_bytes(4, "little") + pos.to_bytes(4, "little")
+            + b"".join(v.to_bytes(4, "little") for v in starts) + b"".join(body))
 
 
 _CODECS = {
-    "blosc": (_no_blosc_write, blosc_decode),
+    "blosc": (blosc_encode, blosc_decode),
     "zlib": (lambda b, cfg: zlib.compress(b, cfg.get("level", 1)), lambda b: zlib.decompress(b)),
     "gzip": (lambda b, cfg: gzip.compress(b, cfg.get("level", 1)), lambda b: gzip.decompress(b)),
     "bz2": (lambda b, cfg: bz2.compress(b, cfg.get("level", 1)), lambda b: bz2.decompress(b)),
@@ -251,7 +285,7 @@ class Array:
         os.makedirs(os.path.dirname(p), exist_ok=True)
         raw = np.asarray(data, dtype=self.dtype).tobytes(order=self.order)
         if self.compressor is not None:
-            raw = _CODECS[self.compressor["id"]][0](raw, self.compressor)
+            raw = _CODECS[self.compressor["id"]][0](raw, {**self.compressor, "_typesize": np.dtype(self.dtype).itemsize})
         tmp = p + f".{os.getpid()}.tmp"
         with _fopen(tmp, "wb") as f:
             f.write(raw)
