@@ -180,6 +180,18 @@ int rg_instnorm_apply(const rg_tensor* x, const float* mean_rstd, const rg_tenso
 int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const rg_tensor* y, const rg_tensor* gy,
                     const rg_tensor* gx, int act, float slope, void* workspace, size_t ws_bytes, rg_stream s);
 
+/* Affine norms — InstanceNormNd(affine=True) and BatchNormNd (NLayerDiscriminator.py:107-115's default norm_layer; a user's norm_layer argument,
+ * networks/ResNet.py:231-262): the same two kernels with a per-channel (gamma, beta) table `gamma_beta` (float2 per channel, NULL = none):
+ *   apply: y = act((x - mean) * rstd * gamma + beta) [+ res]     with whatever (mean, rstd) table the caller built (instance statistics from
+ *          rg_instnorm_stats, batch statistics = their combination over n, or running statistics);
+ *   bwd:   gx = gamma * rstd * (g - m0 - xhat * m1), g = gy * act'(y), (m0, m1) = means of g and g * xhat over the instance, or — batch_stats != 0 —
+ *          over the whole batch.  The (m0, m1) table is left in the workspace behind the partial sums (offset rg_instnorm_workspace_bytes(x),
+ *          float2 per (n, c)): d beta[c] = voxels * sum_n m0, d gamma[c] = voxels * sum_n m1. */
+int rg_norm_apply_affine(const rg_tensor* x, const float* mean_rstd, const float* gamma_beta, const rg_tensor* res, const rg_tensor* y,
+                         int act, float slope, rg_stream s);
+int rg_norm_bwd_affine(const rg_tensor* x, const float* mean_rstd, const float* gamma_beta, int batch_stats, const rg_tensor* y,
+                       const rg_tensor* gy, const rg_tensor* gx, int act, float slope, void* workspace, size_t ws_bytes, rg_stream s);
+
 /* ---- ReflectionPad3d / zero pad (ResNet.py:270,337,392): y = pad(x); bwd folds gy back onto gx. mode 0 zero, 1 reflect. */
 int rg_pad3d_fwd(const rg_tensor* x, const rg_tensor* y, const int32_t pad[3], int mode, rg_stream s);
 int rg_pad3d_bwd(const rg_tensor* gy, const rg_tensor* gx, const int32_t pad[3], int mode, rg_stream s);
@@ -214,6 +226,8 @@ int rg_subpixel_weights_bwd(const float* g_wf, const float* g_weff, const rg_ten
  * kind 1: SmoothL1(beta=1) mean vs tensor t  (LinkCycleLoss.py:22,99-106)
  * kind 2: weighted MSE of WeightedMSELoss_MTLSD._calc_loss (losses/WeightedMSELoss_MTLSD.py:11-25):
  *         out[0]=sum_{w>0} w*(p-t)^2, out[1]=count(w>0), out[2]=count(scaled!=0); grad = grad_scale*2*w*(p-t) (w>0).
+ * kind 3: BCEWithLogitsLoss against the constant const_target (GANLoss "vanilla", losses/GANLoss.py:26-27): out[0]=sum(max(p,0) - p*ct + log(1+exp(-|p|))),
+ *         grad = grad_scale*(sigmoid(p) - ct).   kind 4: out[0]=sum(const_target*p), grad = grad_scale*const_target ("wgangp", GANLoss.py:52-57: ct = -1 real, +1 fake).
  * pred/target/weight/grad: rank-1 contiguous f32 of equal length.  `out` must hold 3 + 3*512 floats (the tail is the
  * per-workgroup partials; the three results are reduced from them in a fixed order). */
 int rg_loss_fwd_bwd(int kind, const rg_tensor* pred, const rg_tensor* target, const rg_tensor* weight, float const_target,

@@ -78,6 +78,8 @@ _SIGS = {
     "rg_instnorm_stats": (C.c_int, [_T, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_instnorm_apply": (C.c_int, [_T, C.c_void_p, _T, _T, C.c_int, C.c_float, C.c_void_p]),
     "rg_instnorm_bwd": (C.c_int, [_T, C.c_void_p, _T, _T, _T, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_norm_apply_affine": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _T, C.c_int, C.c_float, C.c_void_p]),
+    "rg_norm_bwd_affine": (C.c_int, [_T, C.c_void_p, C.c_void_p, C.c_int, _T, _T, _T, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_pad3d_fwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
     "rg_pad3d_bwd": (C.c_int, [_T, _T, _I3, C.c_int, C.c_void_p]),
     "rg_add": (C.c_int, [_T, _T, _T, C.c_void_p]),

@@ -135,14 +135,17 @@ extern "C" int rg_instnorm_stats(const rg_tensor* x, float* mean_rstd, float eps
   return RG_OK;
 }
 
-__global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, int act, float slope, int has_res, int vpb, int dense) {
+// `ab` (optional): per-channel (gamma, beta) of an affine norm: y = act(xhat * gamma + beta) [+ res]
+__global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, const float* ab, int act, float slope, int has_res, int vpb, int dense) {
   const int grp = blockIdx.y * blockDim.x + threadIdx.x, n = blockIdx.z;
   if (grp * 8 >= y.lanes) return;
-  float m[8], r[8];
+  float m[8], r[8], be[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = grp * 8 + k;
     m[k] = c < x.C ? mr[((long)n * x.C + c) * 2] : 0.f; r[k] = c < x.C ? mr[((long)n * x.C + c) * 2 + 1] : 0.f;
+    be[k] = 0.f;
+    if (ab && c < x.C) { r[k] *= ab[2 * c]; be[k] = ab[2 * c + 1]; }
   }
   const unsigned nvox = (unsigned)(y.D * y.H * y.W);
   const unsigned v0 = blockIdx.x * (unsigned)vpb;
@@ -167,7 +170,7 @@ __global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, int ac
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float val = 0.f;
-        if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[u][k]) - m[k]) * r[k], act, slope) + bf2f((bf16_t)rv[u][k]);
+        if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[u][k]) - m[k]) * r[k] + be[k], act, slope) + bf2f((bf16_t)rv[u][k]);
         o[k] = (short)f2bf(val);
       }
       *(bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8) = o;
@@ -188,6 +191,10 @@ static bool same_shape(const CL5& a, const CL5& b) { return a.N == b.N && a.C ==
 
 extern "C" int rg_instnorm_apply(const rg_tensor* x, const float* mean_rstd, const rg_tensor* res, const rg_tensor* y,
                                  int act, float slope, rg_stream s) {
+  return rg_norm_apply_affine(x, mean_rstd, nullptr, res, y, act, slope, s);
+}
+extern "C" int rg_norm_apply_affine(const rg_tensor* x, const float* mean_rstd, const float* gamma_beta, const rg_tensor* res, const rg_tensor* y,
+                                    int act, float slope, rg_stream s) {
   CL5 X, R, Y; int rc;
   if ((rc = rg_as_cl5(x, &X, "instnorm.x")) || (rc = rg_as_cl5(y, &Y, "instnorm.y"))) return rc;
   memset(&R, 0, sizeof(R));
@@ -198,20 +205,23 @@ extern "C" int rg_instnorm_apply(const rg_tensor* x, const float* mean_rstd, con
   dim3 grid, block; int vpb;
   norm_ew_plan(Y, &grid, &block, &vpb);
   const int dense = cl_dense(X) && cl_dense(Y) && (!has_res || cl_dense(R));
-  hipLaunchKernelGGL(norm_apply_kernel, grid, block, 0, (hipStream_t)s, X, R, Y, mean_rstd, act, slope, has_res, vpb, dense);
+  hipLaunchKernelGGL(norm_apply_kernel, grid, block, 0, (hipStream_t)s, X, R, Y, mean_rstd, gamma_beta, act, slope, has_res, vpb, dense);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
 
-__global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, const float* gm, int act, float slope, int vpb, int dense) {
+// `ab` (optional, affine norm): gx = gamma * rstd * (g - mean g - xhat * mean(g xhat)), g = gy * act'(y); the means `gm` are over the instance
+// or, for batch statistics, already averaged over the batch
+__global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, const float* gm, const float* ab, int act, float slope, int vpb, int dense) {
   const int grp = blockIdx.y * blockDim.x + threadIdx.x, n = blockIdx.z;
   if (grp * 8 >= gx.lanes) return;
-  float m[8], r[8], g0[8], g1[8];
+  float m[8], r[8], g0[8], g1[8], ga[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = grp * 8 + k;
     const long q = ((long)n * x.C + (c < x.C ? c : 0)) * 2;
     m[k] = mr[q]; r[k] = mr[q + 1]; g0[k] = gm[q]; g1[k] = gm[q + 1];
+    ga[k] = ab ? ab[2 * (c < x.C ? c : 0)] : 1.f;
   }
   const unsigned nvox = (unsigned)(gx.D * gx.H * gx.W);
   const unsigned v0 = blockIdx.x * (unsigned)vpb;
@@ -240,7 +250,7 @@ __global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, c
         if (grp * 8 + k < x.C) {
           const float g = bf2f((bf16_t)gv[u][k]) * act_bwd_from_y(bf2f((bf16_t)yv[u][k]), act, slope);
           const float xh = (bf2f((bf16_t)xv[u][k]) - m[k]) * r[k];
-          val = r[k] * (g - g0[k] - xh * g1[k]);
+          val = ga[k] * r[k] * (g - g0[k] - xh * g1[k]);
         }
         o[k] = (short)f2bf(val);
       }
@@ -248,8 +258,21 @@ __global__ void norm_bwd_kernel(CL5 x, CL5 y, CL5 gy, CL5 gx, const float* mr, c
     }
   }
 }
+// gm[n][c] <- mean over n (BatchNorm: the statistics, hence the gradient's two means, are over batch x voxels)
+__global__ void norm_batch_avg_kernel(float* gm, int N, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, b = 0;
+  for (int n = 0; n < N; ++n) { a += gm[((long)n * C + c) * 2]; b += gm[((long)n * C + c) * 2 + 1]; }
+  const float fa = (float)(a / N), fb = (float)(b / N);
+  for (int n = 0; n < N; ++n) { gm[((long)n * C + c) * 2] = fa; gm[((long)n * C + c) * 2 + 1] = fb; }
+}
 extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const rg_tensor* y, const rg_tensor* gy,
                                const rg_tensor* gx, int act, float slope, void* workspace, size_t ws_bytes, rg_stream s) {
+  return rg_norm_bwd_affine(x, mean_rstd, nullptr, 0, y, gy, gx, act, slope, workspace, ws_bytes, s);
+}
+extern "C" int rg_norm_bwd_affine(const rg_tensor* x, const float* mean_rstd, const float* gamma_beta, int batch_stats, const rg_tensor* y,
+                                  const rg_tensor* gy, const rg_tensor* gx, int act, float slope, void* workspace, size_t ws_bytes, rg_stream s) {
   CL5 X, Y, GY, GX; int rc;
   if ((rc = rg_as_cl5(x, &X, "instnorm_bwd.x")) || (rc = rg_as_cl5(gy, &GY, "instnorm_bwd.gy")) || (rc = rg_as_cl5(gx, &GX, "instnorm_bwd.gx"))) return rc;
   memset(&Y, 0, sizeof(Y));
@@ -265,11 +288,12 @@ extern "C" int rg_instnorm_bwd(const rg_tensor* x, const float* mean_rstd, const
   hipLaunchKernelGGL((norm_finalize_kernel<1>), dim3(X.N * X.C), dim3(64), 0, (hipStream_t)s, (const float*)workspace, gm, X.N, X.C, X.lanes, p.nblk,
                      (long)X.D * X.H * X.W, 0.f);
   RG_CHECK_LAUNCH();
+  if (batch_stats && X.N > 1) { hipLaunchKernelGGL(norm_batch_avg_kernel, dim3((X.C + 63) / 64), dim3(64), 0, (hipStream_t)s, gm, X.N, X.C); RG_CHECK_LAUNCH(); }
   if ((long)GX.D * GX.H * GX.W >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "instnorm_bwd: more than 2^31 voxels per sample");
   dim3 egrid, eblock; int evpb;
   norm_ew_plan(GX, &egrid, &eblock, &evpb);
   const int dense = cl_dense(X) && cl_dense(GY) && cl_dense(GX) && (act == RG_ACT_NONE || cl_dense(Y));
-  hipLaunchKernelGGL(norm_bwd_kernel, egrid, eblock, 0, (hipStream_t)s, X, Y, GY, GX, mean_rstd, (const float*)gm, act, slope, evpb, dense);
+  hipLaunchKernelGGL(norm_bwd_kernel, egrid, eblock, 0, (hipStream_t)s, X, Y, GY, GX, mean_rstd, (const float*)gm, gamma_beta, act, slope, evpb, dense);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }
@@ -351,6 +375,14 @@ __global__ void loss_kernel(int kind, const float* p, const float* t, const floa
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float pv = p[i];
     if (kind == 0) { const float d = pv - ct; a0 += d * d; if (grad) grad[i] = gscale * 2.f * d; }
+    else if (kind == 3) {   // BCEWithLogitsLoss against the constant target ct (GANLoss "vanilla"): max(x,0) - x ct + log(1 + exp(-|x|))
+      const float e = expf(-fabsf(pv));
+      a0 += fmaxf(pv, 0.f) - pv * ct + log1pf(e);
+      if (grad) grad[i] = gscale * ((pv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e)) - ct);
+    } else if (kind == 4) {   // ct * x (GANLoss "wgangp": -mean(D(x)) for real, +mean for fake)
+      a0 += ct * pv;
+      if (grad) grad[i] = gscale * ct;
+    }
     else if (kind == 1) {
       const float d = pv - t[i], ad = fabsf(d);
       a0 += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
@@ -378,9 +410,9 @@ extern "C" int rg_loss_fwd_bwd(int kind, const rg_tensor* pred, const rg_tensor*
   if (!pred || !pred->ptr || !out || pred->dtype != RG_F32 || pred->rank != 1 || pred->strides[0] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: pred must be flat contiguous f32");
   const long n = pred->sizes[0];
   if (n <= 0) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: empty input");
-  if (kind < 0 || kind > 2) RG_FAIL(RG_ERR_UNSUPPORTED, "loss: kind %d", kind);
+  if (kind < 0 || kind > 4) RG_FAIL(RG_ERR_UNSUPPORTED, "loss: kind %d", kind);
   const float *t = nullptr, *w = nullptr; float* g = nullptr;
-  if (kind >= 1) { if (!target || !target->ptr || target->dtype != RG_F32 || target->sizes[0] != n) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: target"); t = (const float*)target->ptr; }
+  if (kind == 1 || kind == 2) { if (!target || !target->ptr || target->dtype != RG_F32 || target->sizes[0] != n) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: target"); t = (const float*)target->ptr; }
   if (kind == 2) { if (!weight || !weight->ptr || weight->dtype != RG_F32 || weight->sizes[0] != n) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: weight"); w = (const float*)weight->ptr; }
   if (grad && grad->ptr) { if (grad->dtype != RG_F32 || grad->sizes[0] != n) RG_FAIL(RG_ERR_BAD_SHAPE, "loss: grad"); g = (float*)grad->ptr; }
   int nblk = (int)((n + 256 * 8 - 1) / (256 * 8)); if (nblk > LOSS_BLOCKS) nblk = LOSS_BLOCKS; if (nblk < 1) nblk = 1;

@@ -154,12 +154,19 @@ def _instance_norm_run(self, x, act, slope, residual, base_forward, enter=lambda
     """Shared by InstanceNorm3d / InstanceNorm2d.  affine=False runs on the HIP kernels, with or without running statistics
     (torch.nn.modules.instancenorm semantics: instance statistics normalise in training mode and update
     running_mean / running_var — unbiased variance, `momentum`, averaged over the batch — and eval mode normalises with the
-    running statistics); the affine form uses torch's op."""
+    running statistics); the affine form adds the per-channel (gamma, beta) table to the same kernels (ops.norm_affine)."""
     if self.affine:
-        y = passthrough(base_forward, x)
-        if residual is not None:
-            y = ops.add(enter(y), residual)
-        return ops.activation(enter(y), act, slope)
+        x = enter(x)
+        if self.track_running_stats and not self.training:
+            return ops.norm_affine(x, self.weight, self.bias, "fixed", self.eps, act, slope, residual, self.running_mean, self.running_var)[0]
+        y, st = ops.norm_affine(x, self.weight, self.bias, "instance", self.eps, act, slope, residual)
+        if self.track_running_stats:
+            with torch.no_grad():
+                cnt = x.shape[2] * x.shape[3] * x.shape[4]
+                m = self.momentum if self.momentum is not None else 0.0
+                self.running_mean.mul_(1 - m).add_(st[:, :, 0].mean(0).to(self.running_mean.dtype), alpha=m)
+                self.running_var.mul_(1 - m).add_((st[:, :, 1] * (cnt / max(cnt - 1, 1))).mean(0).to(self.running_var.dtype), alpha=m)
+        return y
     x = enter(x)
     if self.track_running_stats and not self.training:
         rstd = torch.rsqrt(self.running_var.float() + self.eps)
@@ -183,10 +190,44 @@ class InstanceNorm3d(nn.InstanceNorm3d):
     networks/ResNet.py:231-262 default) and the running-statistics form of the experiment configs; affine uses torch's op."""
 
     def hip_ok(self):
-        return not self.affine
+        return True
 
     def run(self, x, act="none", slope=0.0, residual=None):
         return _instance_norm_run(self, x, act, slope, residual, super().forward)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+def _batch_norm_run(self, x, act, slope, residual, enter=lambda t: t):
+    """torch.nn.modules.batchnorm semantics on the HIP norm kernels: training mode (or no running statistics) normalises with the mean /
+    biased variance over batch x voxels and updates running_mean / running_var (unbiased variance; `momentum`, or the cumulative average
+    when momentum is None) and num_batches_tracked; eval mode uses the running statistics."""
+    x = enter(x)
+    use_batch = self.training or not self.track_running_stats
+    w, b = (self.weight, self.bias) if self.affine else (None, None)
+    if not use_batch:
+        return ops.norm_affine(x, w, b, "fixed", self.eps, act, slope, residual, self.running_mean, self.running_var)[0]
+    y, st = ops.norm_affine(x, w, b, "batch", self.eps, act, slope, residual)
+    if self.training and self.track_running_stats:
+        with torch.no_grad():
+            self.num_batches_tracked += 1
+            m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+            cnt = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]
+            self.running_mean.mul_(1 - m).add_(st[:, 0].to(self.running_mean.dtype), alpha=m)
+            self.running_var.mul_(1 - m).add_((st[:, 1] * (cnt / max(cnt - 1, 1))).to(self.running_var.dtype), alpha=m)
+    return y
+
+
+class BatchNorm3d(nn.BatchNorm3d):
+    """NLayerDiscriminator3D's default norm_layer (NLayerDiscriminator.py:107-115) on the HIP norm kernels (ops.norm_affine, batch statistics)."""
+
+    def hip_ok(self):
+        return True
+
+    def run(self, x, act="none", slope=0.0, residual=None):
+        return _batch_norm_run(self, x, act, slope, residual)
 
     @scoped
     def forward(self, x):
@@ -268,10 +309,24 @@ class InstanceNorm2d(nn.InstanceNorm2d):
     2-D CycleGAN configs (reference tests/torch/systems/CycleGAN_conf.json:62)."""
 
     def hip_ok(self):
-        return not self.affine
+        return True
 
     def run(self, x, act="none", slope=0.0, residual=None):
         return _instance_norm_run(self, x, act, slope, residual, super().forward, ops.enter)
+
+    @scoped
+    def forward(self, x):
+        return self.run(x)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """NLayerDiscriminator2D's default norm_layer (NLayerDiscriminator.py:8-16), on the (N,C,1,H,W) view."""
+
+    def hip_ok(self):
+        return True
+
+    def run(self, x, act="none", slope=0.0, residual=None):
+        return _batch_norm_run(self, x, act, slope, residual, ops.enter)
 
     @scoped
     def forward(self, x):
@@ -300,9 +355,10 @@ class MaxPool2d(nn.MaxPool2d):
 _HIP_LAYER = {"Conv3d": Conv3d, "ConvTranspose3d": ConvTranspose3d, "InstanceNorm3d": InstanceNorm3d,
               "ReflectionPad3d": ReflectionPad3d, "MaxPool3d": MaxPool3d, "ReLU": ReLU, "LeakyReLU": LeakyReLU,
               "Sigmoid": Sigmoid, "Tanh": Tanh, "Conv2d": Conv2d, "ConvTranspose2d": ConvTranspose2d,
-              "InstanceNorm2d": InstanceNorm2d, "ReflectionPad2d": ReflectionPad2d, "MaxPool2d": MaxPool2d}
+              "InstanceNorm2d": InstanceNorm2d, "ReflectionPad2d": ReflectionPad2d, "MaxPool2d": MaxPool2d,
+              "BatchNorm3d": BatchNorm3d, "BatchNorm2d": BatchNorm2d}
 _CONVS = (Conv3d, ConvTranspose3d, Conv2d, ConvTranspose2d)
-_NORMS = (InstanceNorm3d, InstanceNorm2d)
+_NORMS = (InstanceNorm3d, InstanceNorm2d, BatchNorm3d, BatchNorm2d)
 
 
 def layers(nd):

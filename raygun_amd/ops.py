@@ -1125,6 +1125,97 @@ def instance_norm(x, eps=1e-5, act="none", slope=0.0, residual=None, return_stat
     return (y, mr.view(-1, 2)) if return_stats else y
 
 
+class _NormAffine(Function):
+    """y = act(xhat * gamma + beta) [+ residual] with xhat from instance statistics ("instance": InstanceNormNd(affine=True)), batch statistics
+    ("batch": BatchNormNd in training mode — mean / biased variance over batch x voxels) or a given per-channel table ("fixed": eval mode with
+    running statistics).  gamma / beta may be None (1 / 0).  Returns (y, per-channel or per-(n,c) (mean, biased var) the module needs for its
+    running statistics).  Reference users: NLayerDiscriminator's default norm_layer (NLayerDiscriminator.py:107-115), any norm_layer argument
+    of the generators (networks/ResNet.py:231-262)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, mode, eps, act, slope, fixed_mean, fixed_var):
+        _require_cuda(x, "norm_affine")
+        x = as_cl(x)
+        if res is not None:
+            if act != "none":
+                raise RuntimeError("raygun_amd.norm_affine: residual add is fused only without activation")
+            res = as_cl(res)
+        n, c, d, h, w = x.shape
+        L = _L()
+        dx = desc(x)
+        stats = None
+        if mode == "fixed":
+            rstd = torch.rsqrt(fixed_var.float() + eps)
+            table = torch.stack([fixed_mean.float(), rstd], 1).repeat(n, 1).contiguous().view(-1)
+        else:
+            nbytes = L.rg_instnorm_workspace_bytes(C.byref(dx)) + n * c * 8
+            ws = _debug.empty(nbytes, torch.uint8, x.device)
+            table = _debug.empty(n * c * 2, torch.float32, x.device)
+            _lib.check(L.rg_instnorm_stats(C.byref(dx), C.c_void_p(table.data_ptr()), float(eps), C.c_void_p(ws.data_ptr()), nbytes, _stream()),
+                       "rg_instnorm_stats")
+            t = table.view(n, c, 2)
+            mean_nc, var_nc = t[:, :, 0], (1.0 / (t[:, :, 1] * t[:, :, 1]) - eps).clamp_(min=0)
+            if mode == "batch":
+                mean_c = mean_nc.mean(0)
+                var_c = ((var_nc + mean_nc * mean_nc).mean(0) - mean_c * mean_c).clamp_(min=0)
+                table = torch.stack([mean_c, torch.rsqrt(var_c + eps)], 1).repeat(n, 1).contiguous().view(-1)
+                stats = torch.stack([mean_c, var_c], 1)                     # (C, 2)
+            else:
+                stats = torch.stack([mean_nc, var_nc], 2)                   # (N, C, 2)
+        gb = None
+        if gamma is not None or beta is not None:
+            g1 = gamma.detach().float() if gamma is not None else torch.ones(c, device=x.device)
+            b1 = beta.detach().float() if beta is not None else torch.zeros(c, device=x.device)
+            gb = torch.stack([g1, b1], 1).contiguous().view(-1)
+        y = cl_empty(n, c, d, h, w, x.device)
+        _lib.check(L.rg_norm_apply_affine(C.byref(dx), C.c_void_p(table.data_ptr()), C.c_void_p(gb.data_ptr()) if gb is not None else None,
+                                          C.byref(desc(res)) if res is not None else None, C.byref(desc(y)), ACT[act], float(slope), _stream()),
+                   "rg_norm_apply_affine")
+        ctx.save_for_backward(x, table, gb, y if act != "none" else None)
+        ctx.cfg = (mode, act, slope, res is not None, gamma is not None, beta is not None)
+        if stats is None:
+            stats = table.new_zeros(0)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, gy, _gstats=None):
+        x, table, gb, y = ctx.saved_tensors
+        mode, act, slope, has_res, has_g, has_b = ctx.cfg
+        gy = as_cl(gy)
+        n, c, d, h, w = x.shape
+        nvox = d * h * w
+        L = _L()
+        dx = desc(x)
+        part = L.rg_instnorm_workspace_bytes(C.byref(dx))
+        nbytes = part + n * c * 8
+        ws = _debug.empty(nbytes, torch.uint8, x.device)
+        gx = cl_empty(n, c, d, h, w, x.device)
+        # (fixed statistics: the two means are still reduced — they are d beta / d gamma — but gx must not subtract them: see below)
+        _lib.check(L.rg_norm_bwd_affine(C.byref(dx), C.c_void_p(table.data_ptr()), C.c_void_p(gb.data_ptr()) if gb is not None else None,
+                                        1 if mode == "batch" else 0, C.byref(desc(y)) if y is not None else None, C.byref(desc(gy)), C.byref(desc(gx)),
+                                        ACT[act], float(slope), C.c_void_p(ws.data_ptr()), nbytes, _stream()), "rg_norm_bwd_affine")
+        gm = ws[part:part + n * c * 8].view(torch.float32).view(n, c, 2)
+        dbeta = (gm[:, :, 0].sum(0) * nvox) if has_b else None
+        dgamma = (gm[:, :, 1].sum(0) * nvox) if has_g else None
+        if mode == "fixed":   # constants, not statistics of x: gx = gamma * rstd * g, through the apply kernel with a (0, rstd) table
+            g, _ = _act_bwd_bias(gy, y, act, slope, False)
+            t0 = table.view(-1, 2).clone(); t0[:, 0] = 0
+            gonly = None
+            if gb is not None:
+                gonly = gb.view(-1, 2).clone(); gonly[:, 1] = 0; gonly = gonly.view(-1)
+            _lib.check(L.rg_norm_apply_affine(C.byref(desc(g)), C.c_void_p(t0.data_ptr()), C.c_void_p(gonly.data_ptr()) if gonly is not None else None, None,
+                                              C.byref(desc(gx)), ACT["none"], 0.0, _stream()), "rg_norm_apply_affine")
+        if not ctx.needs_input_grad[0]:
+            gx = None
+        return gx, (gy if has_res and ctx.needs_input_grad[1] else None), dgamma, dbeta, None, None, None, None, None, None
+
+
+def norm_affine(x, gamma, beta, mode="instance", eps=1e-5, act="none", slope=0.0, residual=None, mean=None, var=None):
+    """(y, stats): see _NormAffine.  mode "fixed" takes the per-channel `mean` / `var` (running statistics)."""
+    return _NormAffine.apply(x, residual, gamma, beta, mode, float(eps), act, float(slope), mean, var)
+
+
 class _NormFixed(Function):
     """y = act((x - mean[c]) * rstd[c]) [+ residual] with GIVEN per-channel statistics — InstanceNorm(track_running_stats=True) in
     eval mode (the CycleGAN's `freeze_norms_at` / set_norm_mode("fix_norms"), networks/utils.py:31-42, models/FreezableModel.py):
@@ -1352,6 +1443,16 @@ class _Loss(Function):
 
 def mse_const(pred, target_value):
     return _Loss.apply(0, pred, None, None, float(target_value))
+
+
+def bce_logits_const(pred, target_value):
+    """BCEWithLogitsLoss(pred, full_like(pred, target_value)) (GANLoss "vanilla")."""
+    return _Loss.apply(3, pred, None, None, float(target_value))
+
+
+def mean_signed(pred, sign):
+    """sign * mean(pred) (GANLoss "wgangp": -mean for real, +mean for fake)."""
+    return _Loss.apply(4, pred, None, None, float(sign))
 
 
 def smooth_l1(pred, target):

@@ -1,5 +1,5 @@
 """GAN objectives — drop-in for raygun.torch.losses.GANLoss (reference: losses/GANLoss.py:5-64).
-lsgan on a GPU tensor is one fused value+gradient kernel (rg_loss_fwd_bwd kind 0)."""
+every mode is one fused value+gradient kernel (rg_loss_fwd_bwd kind 0 lsgan, 3 vanilla, 4 wgangp)."""
 import torch
 
 from ... import ops
@@ -28,6 +28,12 @@ class GANLoss(torch.nn.Module):
     def __call__(self, prediction, target_is_real):
         if self.gan_mode == "lsgan":
             return ops.mse_const(prediction, self._labels[0] if target_is_real else self._labels[1])
+        if not prediction.is_cuda:
+            # plain torch modules on host tensors: only the CPU suite's host-logic tests of the loss classes come this way (vanilla /
+            # wgangp, as in the reference); lsgan above has no such branch — the HIP ops raise on CPU tensors
+            if self.gan_mode == "vanilla":
+                return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
+            return -prediction.mean() if target_is_real else prediction.mean()
         if self.gan_mode == "vanilla":
-            return self.loss(prediction, self.get_target_tensor(prediction, target_is_real))
-        return -prediction.mean() if target_is_real else prediction.mean()
+            return ops.bce_logits_const(prediction, self._labels[0] if target_is_real else self._labels[1])
+        return ops.mean_signed(prediction, -1.0 if target_is_real else 1.0)

@@ -258,6 +258,82 @@ def test_losses():
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 1e-6 + 1e-5 * float(b.grad.abs().max())
 
 
+@pytest.mark.parametrize("kind,nd,act", [("instance", 3, "none"), ("instance", 3, "relu"), ("instance_rs", 2, "leaky"), ("batch", 3, "leaky"),
+                                         ("batch", 2, "none"), ("batch_nomom", 3, "relu"), ("batch_noaffine", 3, "none")])
+def test_affine_instance_norm_and_batch_norm_match_torch(kind, nd, act):
+    """InstanceNormNd(affine=True[, track_running_stats]) and BatchNormNd (training: batch statistics + running-statistics update incl.
+    num_batches_tracked and momentum=None; eval: running statistics) on the HIP norm kernels (ops.norm_affine) against torch.nn on the CPU
+    with bf16-exact inputs: outputs, input gradient, d gamma / d beta, the running buffers after two training steps, and an eval pass."""
+    from raygun_amd import hipnn
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    c, n = 12, 3
+    shape = (n, c, 5, 6, 7) if nd == 3 else (n, c, 9, 10)
+    tname = ("InstanceNorm" if kind.startswith("instance") else "BatchNorm") + f"{nd}d"
+    kw = {"instance": dict(affine=True), "instance_rs": dict(affine=True, track_running_stats=True, momentum=0.05), "batch": dict(momentum=0.2),
+          "batch_nomom": dict(momentum=None), "batch_noaffine": dict(affine=False)}[kind]
+    ref = getattr(torch.nn, tname)(c, **kw)
+    mine = getattr(hipnn, tname)(c, **kw)
+    if kw.get("affine", True):
+        with torch.no_grad():
+            ref.weight.copy_(torch.randn(c, generator=g) * 0.5 + 1.0); ref.bias.copy_(torch.randn(c, generator=g) * 0.3)
+    mine.load_state_dict(ref.state_dict()); mine = mine.to(dev)
+    aref = {"none": lambda t: t, "relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    seq = hipnn.FusedSequential(*([mine] + ({"none": [], "relu": [hipnn.ReLU()], "leaky": [hipnn.LeakyReLU(0.2)]}[act])))   # norm + activation fuse
+    for it in range(2):
+        x0 = (torch.randn(shape, generator=g) * 1.5 + 0.3).bfloat16().float()
+        gy = torch.randn(shape, generator=g).bfloat16().float()
+        xr = x0.clone().requires_grad_(True); xm = x0.clone().to(dev).requires_grad_(True)
+        yr = aref(ref(xr)); yr.backward(gy)
+        ym = seq(xm); ym.backward(gy.to(dev))
+        assert ym.shape == yr.shape and ym.dtype == torch.float32
+        assert float((ym.detach().cpu() - yr.detach()).abs().max()) <= 2e-2 * max(1.0, float(yr.abs().max())), (kind, it)
+        assert float((xm.grad.cpu() - xr.grad).abs().max()) <= 2e-2 * max(1.0, float(xr.grad.abs().max())), (kind, it)
+        if kw.get("affine", True):
+            for a, b in ((mine.weight.grad, ref.weight.grad), (mine.bias.grad, ref.bias.grad)):
+                assert float((a.cpu() - b).abs().max()) <= 1.5e-2 * max(1.0, float(b.abs().max())), (kind, it)
+            mine.zero_grad(); ref.zero_grad()
+        if getattr(ref, "track_running_stats", False):
+            assert torch.allclose(mine.running_mean.cpu(), ref.running_mean, rtol=1e-4, atol=1e-5)
+            assert torch.allclose(mine.running_var.cpu(), ref.running_var, rtol=2e-4, atol=1e-5)
+            if hasattr(ref, "num_batches_tracked") and ref.num_batches_tracked is not None and tname.startswith("Batch"):
+                assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == it + 1
+    if getattr(ref, "track_running_stats", False):
+        ref.eval(); mine.eval()
+        x0 = torch.randn(shape, generator=g).bfloat16().float()
+        xr = x0.clone().requires_grad_(True); xm = x0.clone().to(dev).requires_grad_(True)
+        gy = torch.randn(shape, generator=g).bfloat16().float()
+        yr = aref(ref(xr)); yr.backward(gy)
+        ym = seq(xm); ym.backward(gy.to(dev))
+        assert float((ym.detach().cpu() - yr.detach()).abs().max()) <= 2e-2 * max(1.0, float(yr.abs().max()))
+        assert float((xm.grad.cpu() - xr.grad).abs().max()) <= 2e-2 * max(1.0, float(xr.grad.abs().max()))
+        if kw.get("affine", True):
+            assert float((mine.weight.grad.cpu() - ref.weight.grad).abs().max()) <= 1.5e-2 * max(1.0, float(ref.weight.grad.abs().max()))
+            assert float((mine.bias.grad.cpu() - ref.bias.grad).abs().max()) <= 1.5e-2 * max(1.0, float(ref.bias.grad.abs().max()))
+
+
+def test_gan_losses_vanilla_and_wgangp_on_the_fused_kernel():
+    """GANLoss "vanilla" (BCEWithLogitsLoss against the constant label) and "wgangp" (-/+ mean) as rg_loss_fwd_bwd kinds 3 / 4: value and
+    gradient against torch on the same fp32 logits, incl. large |x| (the stable log(1 + exp(-|x|)) form) and smoothed labels."""
+    from raygun_amd.torch.losses.GANLoss import GANLoss
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    x0 = (torch.randn(2, 1, 7, 6, 5, generator=g) * 4).to(dev)
+    x0.view(-1)[:4] = torch.tensor([60.0, -60.0, 0.0, 1e-4], device=dev)
+    for mode, labels in (("vanilla", (1.0, 0.0)), ("vanilla", (0.9, 0.1)), ("wgangp", (1.0, 0.0))):
+        for real in (True, False):
+            x = x0.clone().requires_grad_(True); xr = x0.clone().requires_grad_(True)
+            crit = GANLoss(mode, *labels).to(dev)
+            loss = crit(x, real)
+            if mode == "vanilla":
+                ref = F.binary_cross_entropy_with_logits(xr, torch.full_like(xr, labels[0] if real else labels[1]))
+            else:
+                ref = -xr.mean() if real else xr.mean()
+            (loss * 3).backward(); (ref * 3).backward()
+            assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (mode, real)
+            assert torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-8), (mode, real)
+
+
 def test_adam_matches_torch():
     from raygun_amd import ops
     dev = torch.device("cuda")
