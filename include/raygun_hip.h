@@ -274,6 +274,10 @@ int rg_mws_stats(const void* workspace, const rg_mws_params* p, uint64_t out[8],
  * rounded exactly as numpy does in float32.  affs / weights: (n_offsets, n_voxels) float32 (may not alias), mask: n_voxels bytes. */
 int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,
                    float thresh, rg_stream s);
+/* the same from uint8 affinities (what the block runner stores for integer destinations, worker.py:133-144): a = (float)u8 * scale in
+ * float32, i.e. bit for bit rg_mws_prepare(affs8.astype(float32) * scale) without the float array. */
+int rg_mws_prepare_u8(const uint8_t* affs, float scale, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets,
+                      int32_t n_attractive, float thresh, rg_stream s);
 
 
 /* ---- slab decomposition of the mutex watershed (no reference counterpart: affogato segments one in-memory array; SURVEY.md 8e,

@@ -89,6 +89,33 @@ __global__ __launch_bounds__(256) void mws_prepare_kernel(const float* affs, flo
   }
   mask[u] = __fdiv_rn(sum, (float)n_off) > thresh ? 1 : 0;
 }
+// The same from the uint8 affinities the block runner stores for integer destinations (worker.py:133-144: value * 255, clamped, cast):
+// a = (float)u8 * scale in float32 — what `affs8.astype(float32) * scale` gives — without the 4-byte-per-value intermediate (config 5's
+// 2048^3 / 8 part: 86 GB of float affinities that exist only to be read once).
+__global__ __launch_bounds__(256) void mws_prepare_u8_kernel(const unsigned char* affs, float scale, float* weights, unsigned char* mask, long N,
+                                                            int n_off, int n_attr, float thresh) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  float sum = 0.f;
+  for (int k = 0; k < n_off; ++k) {
+    const float a = __fmul_rn((float)affs[(long)k * N + u], scale);
+    sum = k ? __fadd_rn(sum, a) : a;
+    float w = __fsub_rn(1.f, a);
+    if (k < n_attr) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f);
+    weights[(long)k * N + u] = w;
+  }
+  mask[u] = __fdiv_rn(sum, (float)n_off) > thresh ? 1 : 0;
+}
+extern "C" int rg_mws_prepare_u8(const uint8_t* affs, float scale, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets,
+                                 int32_t n_attractive, float thresh, rg_stream s) {
+  if (!affs || !weights || !mask || n_voxels <= 0 || n_offsets <= 0 || n_attractive < 0 || n_attractive > n_offsets)
+    RG_FAIL(RG_ERR_BAD_SHAPE, "mws_prepare_u8: bad arguments");
+  if ((n_voxels + 255) / 256 > 0x7fffffffL) RG_FAIL(RG_ERR_UNSUPPORTED, "mws_prepare_u8: volume too large");
+  hipLaunchKernelGGL(mws_prepare_u8_kernel, dim3((unsigned)((n_voxels + 255) / 256)), dim3(256), 0, (hipStream_t)s, affs, scale, weights, mask,
+                     (long)n_voxels, n_offsets, n_attractive, thresh);
+  RG_CHECK_LAUNCH();
+  return RG_OK;
+}
 extern "C" int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,
                               float thresh, rg_stream s) {
   if (!affs || !weights || !mask || n_voxels <= 0 || n_offsets <= 0 || n_attractive < 0 || n_attractive > n_offsets)

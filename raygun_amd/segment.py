@@ -23,6 +23,22 @@ from .read_config import read_config
 DEFAULT_NEIGHBORHOOD = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 0, 0], [0, 2, 0], [0, 0, 2],
                         [4, 0, 0], [0, 4, 0], [0, 0, 4], [8, 0, 0], [0, 8, 0], [0, 0, 8]]
 
+_SEG_TIMING = bool(os.environ.get("RAYGUN_AMD_SEG_TIMING"))   # diagnostics: stage times of segment_slabs / pipeline on stderr (synchronises)
+_seg_t = [0.0]
+
+
+def _stage(tag, dev=None):
+    if not _SEG_TIMING:
+        return
+    import sys
+    import time
+    torch.cuda.synchronize(dev)
+    now = time.perf_counter()
+    if tag is not None:
+        sys.stderr.write(f"[seg] {tag}: {(now - _seg_t[0]) * 1e3:.1f} ms  (allocated {torch.cuda.memory_allocated(dev) / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved(dev) / 2**30:.1f} GiB)\n")
+    _seg_t[0] = time.perf_counter()
+
+
 
 def build_neighborhood(neighborhood=None, n_diagonals=8):
     """segment.py:144-157,173-181: 12 axis offsets + n in-plane diagonals (int8)."""
@@ -125,6 +141,25 @@ def prepare_weights(affs, sep, mask_thresh, max_affinity_value, device=None):
     return w, m
 
 
+def prepare_weights_u8(affs8, scale, sep, mask_thresh, max_affinity_value, device=None):
+    """prepare_weights(affs8.float() * scale, ...) bit for bit, without the float32 affinities: affs8 is the (n_offsets, Z, Y, X) uint8 tensor the
+    block runner leaves on the device (worker.py:133-144 stores value * 255 for integer destinations; scale = 1 / 255 takes it back to [0, 1])."""
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda" or not (torch.is_tensor(affs8) and affs8.is_cuda and affs8.dtype == torch.uint8):
+        raise RuntimeError("raygun_amd.prepare_weights_u8: a uint8 tensor on the MI355X expected (no CPU fallback)")
+    a = affs8.contiguous()
+    if a.dim() != 4:
+        raise ValueError(f"affs must be (n_offsets, Z, Y, X); got {tuple(a.shape)}")
+    w = torch.empty(tuple(a.shape), dtype=torch.float32, device=dev)
+    m = torch.empty(tuple(a.shape[1:]), dtype=torch.uint8, device=dev)
+    if m.numel():
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().rg_mws_prepare_u8(C.c_void_p(a.data_ptr()), float(np.float32(scale)), C.c_void_p(w.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                    m.numel(), a.shape[0], int(sep), float(np.float32(mask_thresh * max_affinity_value)),
+                                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_prepare_u8")
+    return w, m
+
+
 SINGLE_PASS_EDGE_IDS = 2 ** 32 - 2 ** 24   # one rg_mws_segment pass numbers its edges n_offsets * voxels < 2^32
 
 
@@ -199,6 +234,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     L = _lib.lib()
     st = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)  # noqa: E731
     # ---- 1. first level
+    _stage(None, dev)
     labs, counts = [], []
     for zs, t in mine:
         zl = zs - zbase
@@ -208,6 +244,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
         if int(lab.view(-1)[0].item()) == -1:
             raise RuntimeError("raygun_amd.segment_slabs: the device pass made no progress (internal error)")
         labs.append(lab); counts.append(int(lab.max().item()))
+        _stage(f"first level, slab z={zs} t={t}", dev)
     if distributed:   # global slab list = every rank's sub-slabs, in rank order
         per_rank = parallel.all_gather_ints(counts, group)
         assert [len(c) for c in per_rank] == nsub
@@ -280,6 +317,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
                 raise RuntimeError("raygun_amd.segment_slabs: mutex-pair capacity exceeded (internal error)")
             pr = torch.unique(pairs[:n])
             mut.append(torch.stack([(pr >> 32) + int(bases[sid]), (pr & 0xffffffff) + int(bases[sid])], 1))
+    _stage("zones + cross edges + slab mutexes", dev)
     cat = lambda xs, dt: torch.cat(xs) if xs else torch.zeros(0, dtype=dt, device=dev)  # noqa: E731
     wkey, gid, gu, gv, attr = cat(rec["wkey"], torch.int32), cat(rec["gid"], torch.int64), cat(rec["gu"], torch.int64), cat(rec["gv"], torch.int64), cat(rec["attr"], torch.uint8)
     mutp = torch.cat(mut) if mut else torch.zeros((0, 2), dtype=torch.int64, device=dev)
@@ -311,6 +349,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
             raise RuntimeError("raygun_amd.segment_slabs: the second-level pass made no progress (internal error)")
         rep_g = nodes[rep.long()]
     nonrep = nodes[rep_g != nodes]                       # sorted: clusters that merged into a smaller id
+    _stage(f"second level ({n_nodes} nodes, {int(wkey.numel())} cross edges, {int(mutp.shape[0])} mutexes)", dev)
     # ---- 4. relabel: final label = rank of the cluster's representative among all representatives
     outs = []
     for sid, lab in zip(my_ids, labs):
@@ -326,6 +365,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
             _lib.check(L.rg_mws_relabel(C.c_void_p(lab.data_ptr()), C.c_void_p(lut.data_ptr()), lab.numel(), st()), "rg_mws_relabel")
         outs.append(lab)
     out = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+    _stage("relabel + concatenate", dev)
     return out if as_tensor else out.cpu().numpy().astype(np.uint64)
 
 

@@ -123,6 +123,29 @@ def test_gpu_prepare_bit_exact():
 
 
 @pytest.mark.gpu
+def test_gpu_prepare_from_uint8_bit_exact():
+    """rg_mws_prepare_u8 (the block runner's uint8 affinities, scaled inside the kernel) == the numpy float32 arithmetic of segment.py:188-194 on
+    `affs8.astype(float32) * float32(1/255)` — oracle.mws.prepare — bit for bit, and == the float kernel on the same float array."""
+    import torch
+    from raygun_amd.segment import prepare_weights, prepare_weights_u8
+    shape = (7, 13, 19)
+    rng = np.random.default_rng(8)
+    a8 = rng.integers(0, 256, size=(20,) + shape, dtype=np.uint8)
+    a8[:, 0, 0, :4] = np.array([127, 128, 0, 255], np.uint8)     # channel means right around the threshold, and the range ends
+    scale = np.float32(1.0 / 255.0)
+    af = a8.astype(np.float32) * scale
+    for sep, thresh in ((3, 0.5), (5, 0.25)):
+        ww, m = O.prepare(af.copy(), sep, thresh, 1.0)
+        w, mk = prepare_weights_u8(torch.from_numpy(a8).cuda(), float(scale), sep, thresh, 1.0)
+        assert (w.cpu().numpy().view(np.uint32) == ww.view(np.uint32)).all()
+        assert (mk.cpu().numpy().astype(bool) == m).all()
+        w2, mk2 = prepare_weights(af.copy(), sep, thresh, 1.0)
+        assert torch.equal(w, w2) and torch.equal(mk, mk2)
+    with pytest.raises(RuntimeError):
+        prepare_weights_u8(torch.from_numpy(a8), float(scale), 3, 0.5, 1.0)       # host tensor: no CPU fallback
+
+
+@pytest.mark.gpu
 def test_gpu_ties_and_empty():
     from raygun_amd.segment import compute_mws_segmentation
     # every weight equal: the tie order (ascending edge id) decides everything
