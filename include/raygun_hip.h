@@ -267,6 +267,13 @@ int64_t rg_mws_workspace_bytes(const rg_mws_params* p);
  */
 int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels,
                    const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s);
+/* The same pass reading the block runner's uint8 affinities (worker.py:133-144: value * 255) with the preprocessing of segment.py:188-194 applied on
+ * the fly, bit for bit: a = (float)u8 * scale, w = 1 - a, channels below `prepare_sep` flipped back (w * -1 + 1) — i.e. rg_mws_segment on the output
+ * of rg_mws_prepare_u8 without the float32 weight array (4 bytes per value: 87 GB for config 5's 2048^3 / 8 part).  `channel_stride`: elements
+ * between channels (>= voxels of `p->shape`: a Z-slab of a larger volume is addressed in place).  `mask` as before (rg_mws_prepare_u8 with weights =
+ * NULL computes it alone). */
+int rg_mws_segment_u8(const uint8_t* affs8, float scale, int32_t prepare_sep, int64_t channel_stride, const int32_t* offsets, const uint8_t* mask,
+                      uint64_t* labels, const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s);
 /* Diagnostics of the last rg_mws_segment run that used `workspace`: out = {edges, rounds, window visits, 100-MHz ticks in phase
  * A, B, C of the round kernel, mutex-list nodes, 0}.  Synchronises the stream. */
 int rg_mws_stats(const void* workspace, const rg_mws_params* p, uint64_t out[8], rg_stream s);
@@ -275,7 +282,7 @@ int rg_mws_stats(const void* workspace, const rg_mws_params* p, uint64_t out[8],
 int rg_mws_prepare(const float* affs, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets, int32_t n_attractive,
                    float thresh, rg_stream s);
 /* the same from uint8 affinities (what the block runner stores for integer destinations, worker.py:133-144): a = (float)u8 * scale in
- * float32, i.e. bit for bit rg_mws_prepare(affs8.astype(float32) * scale) without the float array. */
+ * float32, i.e. bit for bit rg_mws_prepare(affs8.astype(float32) * scale) without the float array.  weights == NULL: the mask only. */
 int rg_mws_prepare_u8(const uint8_t* affs, float scale, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets,
                       int32_t n_attractive, float thresh, rg_stream s);
 
@@ -292,6 +299,10 @@ int rg_mws_prepare_u8(const uint8_t* affs, float scale, float* weights, uint8_t*
 int rg_mws_cross_edges(const float* weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
                        int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
                        int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s);
+/* rg_mws_cross_edges reading uint8 affinities as rg_mws_segment_u8 does (same scale / prepare_sep / channel_stride). */
+int rg_mws_cross_edges_u8(const uint8_t* affs8, float scale, int32_t prepare_sep, int64_t channel_stride, const int64_t* labels, int64_t base_own,
+                          const int64_t* nzone, int32_t H, int32_t dir, int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p,
+                          uint32_t* wkey, uint64_t* gid, int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s);
 int rg_mws_slab_mutexes(const int64_t* labels, const uint8_t* is_node, const int32_t* offsets, const rg_mws_params* p, uint64_t* pairs,
                         uint32_t* count, uint32_t cap, rg_stream s);
 int64_t rg_mws_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges);

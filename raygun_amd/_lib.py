@@ -111,6 +111,10 @@ _SIGS = {
     "rg_mws_stats": (C.c_int, [C.c_void_p, _P(rg_mws_params), C.c_void_p, C.c_void_p]),
     "rg_mws_cross_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, _P(rg_mws_params),
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rg_mws_cross_edges_u8": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                        _P(rg_mws_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rg_mws_segment_u8": (C.c_int, [C.c_void_p, C.c_float, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p,
+                                    C.c_size_t, C.c_void_p]),
     "rg_mws_slab_mutexes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _P(rg_mws_params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rg_mws_graph_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "rg_mws_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
@@ -119,7 +123,7 @@ _SIGS = {
 }
 
 DECLARED = sorted(_SIGS)
-_F16_ABSENT = {"rg_add_affinities", "rg_balance_labels_workspace_bytes", "rg_balance_labels", "rg_lsd_targets", "rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_prepare_u8", "rg_mws_segment", "rg_mws_stats", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
+_F16_ABSENT = {"rg_add_affinities", "rg_balance_labels_workspace_bytes", "rg_balance_labels", "rg_lsd_targets", "rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_prepare_u8", "rg_mws_segment", "rg_mws_segment_u8", "rg_mws_cross_edges_u8", "rg_mws_stats", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
                "rg_mws_graph_workspace_bytes", "rg_mws_graph", "rg_mws_relabel"}  # no 16-bit data on the mutex-watershed path
 _libs = {}
 import threading

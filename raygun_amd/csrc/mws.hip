@@ -32,8 +32,20 @@ __device__ __forceinline__ unsigned order_desc(float w) {
 // One thread per voxel: the (z, y, x) decode and the stride-grid test happen once, only the channels that can hold an edge
 // are read (3 attractive ones for 999 voxels in 1000 at stride 10), and a 1024-voxel workgroup reserves its keys with ONE
 // atomic (one per wavefront was the bottleneck: 262 144 serialised atomics on one counter at 256^3).
+// Where an edge weight comes from: the float32 weight array of the reference pipeline (scale == 0: segment.py:188-194 ran before), or the block
+// runner's uint8 affinities with that preprocessing applied on the fly, in the same float32 roundings — a = u8 * scale, w = 1 - a, and the first
+// `prep_sep` channels flipped back as w * -1 + 1 — so that the 4-byte-per-value weight array (87 GB for config 5's 2048^3 / 8 part) never exists.
+// `cstride`: elements between channels (a Z-slab of a larger volume is a view, not a copy).
+struct MwsSrc { const void* p; long cstride; float scale; int prep_sep; };
+__device__ __forceinline__ float mws_src(const MwsSrc& a, int k, long u) {
+  if (a.scale == 0.f) return ((const float*)a.p)[(long)k * a.cstride + u];
+  const float v = __fmul_rn((float)((const unsigned char*)a.p)[(long)k * a.cstride + u], a.scale);
+  float w = __fsub_rn(1.f, v);
+  if (k < a.prep_sep) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f);
+  return w;
+}
 #define MWS_EDGE_THREADS 1024
-__global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(const float* affs, const int* offsets, const unsigned char* mask, u64* keys,
+__global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(MwsSrc affs, const int* offsets, const unsigned char* mask, u64* keys,
                                                                     unsigned* count, int Z, int Y, int X, int n_off, int n_attr, int sz, int sy, int sx,
                                                                     int oz, int oy, int ox, int invert, float bias) {
   __shared__ unsigned wave_base[MWS_EDGE_THREADS / 64];
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(MWS_EDGE_THREADS) void mws_edges_kernel(const float
   while (valid) {
     const int k = __builtin_ctzll(valid); valid &= valid - 1;
     const unsigned id = (unsigned)k * N + u;
-    float w = affs[id];  // affogato's wrapper, in float32: w[n_attr:] = w[n_attr:] * -1 + 1 (invert_repulsive_weights), w[:n_attr] += bias_cut
+    float w = mws_src(affs, k, (long)u);  // affogato's wrapper, in float32: w[n_attr:] = w[n_attr:] * -1 + 1 (invert_repulsive_weights), w[:n_attr] += bias_cut
     if (k >= n_attr) { if (invert) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f); }
     else w = __fadd_rn(w, bias);
     keys[pos++] = ((u64)order_desc(w) << 32) | (u64)id;
@@ -100,15 +112,17 @@ __global__ __launch_bounds__(256) void mws_prepare_u8_kernel(const unsigned char
   for (int k = 0; k < n_off; ++k) {
     const float a = __fmul_rn((float)affs[(long)k * N + u], scale);
     sum = k ? __fadd_rn(sum, a) : a;
-    float w = __fsub_rn(1.f, a);
-    if (k < n_attr) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f);
-    weights[(long)k * N + u] = w;
+    if (weights) {
+      float w = __fsub_rn(1.f, a);
+      if (k < n_attr) w = __fadd_rn(__fmul_rn(w, -1.f), 1.f);
+      weights[(long)k * N + u] = w;
+    }
   }
   mask[u] = __fdiv_rn(sum, (float)n_off) > thresh ? 1 : 0;
 }
 extern "C" int rg_mws_prepare_u8(const uint8_t* affs, float scale, float* weights, uint8_t* mask, int64_t n_voxels, int32_t n_offsets,
                                  int32_t n_attractive, float thresh, rg_stream s) {
-  if (!affs || !weights || !mask || n_voxels <= 0 || n_offsets <= 0 || n_attractive < 0 || n_attractive > n_offsets)
+  if (!affs || !mask || n_voxels <= 0 || n_offsets <= 0 || n_attractive < 0 || n_attractive > n_offsets)   // weights == NULL: the mask only
     RG_FAIL(RG_ERR_BAD_SHAPE, "mws_prepare_u8: bad arguments");
   if ((n_voxels + 255) / 256 > 0x7fffffffL) RG_FAIL(RG_ERR_UNSUPPORTED, "mws_prepare_u8: volume too large");
   hipLaunchKernelGGL(mws_prepare_u8_kernel, dim3((unsigned)((n_voxels + 255) / 256)), dim3(256), 0, (hipStream_t)s, affs, scale, weights, mask,
@@ -461,13 +475,28 @@ extern "C" int64_t rg_mws_workspace_bytes(const rg_mws_params* p) {
   return (int64_t)q.total;
 }
 
+static int mws_segment_src(MwsSrc affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels, const rg_mws_params* p, void* workspace,
+                           size_t ws_bytes, rg_stream s);
 extern "C" int rg_mws_segment(const float* affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels,
                               const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s) {
+  if (!p) RG_FAIL(RG_ERR_BAD_SHAPE, "mws: null parameters");
+  const MwsSrc src = {affs, (long)p->shape[0] * p->shape[1] * p->shape[2], 0.f, 0};
+  return mws_segment_src(src, offsets, mask, labels, p, workspace, ws_bytes, s);
+}
+extern "C" int rg_mws_segment_u8(const uint8_t* affs8, float scale, int32_t prepare_sep, int64_t channel_stride, const int32_t* offsets,
+                                 const uint8_t* mask, uint64_t* labels, const rg_mws_params* p, void* workspace, size_t ws_bytes, rg_stream s) {
+  if (!p || scale == 0.f || prepare_sep < 0 || channel_stride < (int64_t)p->shape[0] * p->shape[1] * p->shape[2])
+    RG_FAIL(RG_ERR_BAD_SHAPE, "mws_segment_u8: bad scale / prepare_sep / channel stride");
+  const MwsSrc src = {affs8, (long)channel_stride, scale, prepare_sep};
+  return mws_segment_src(src, offsets, mask, labels, p, workspace, ws_bytes, s);
+}
+static int mws_segment_src(MwsSrc affs, const int32_t* offsets, const uint8_t* mask, uint64_t* labels, const rg_mws_params* p, void* workspace,
+                           size_t ws_bytes, rg_stream s) {
   MwsPlan q;
   const int rc = mws_plan(p, &q);
   if (rc == -2) RG_FAIL(RG_ERR_UNSUPPORTED, "mws: volume too large for one segment (n_offsets*N must be < 2^32): split into blocks");
   if (rc) RG_FAIL(RG_ERR_BAD_SHAPE, "mws: bad parameters (randomize_strides is not supported)");
-  if (!affs || !offsets || !labels) RG_FAIL(RG_ERR_BAD_SHAPE, "mws: null pointer");
+  if (!affs.p || !offsets || !labels) RG_FAIL(RG_ERR_BAD_SHAPE, "mws: null pointer");
   if (!workspace || ws_bytes < q.total) RG_FAIL(RG_ERR_WORKSPACE, "mws: workspace %zu < %zu bytes", ws_bytes, q.total);
   hipStream_t st = (hipStream_t)s;
   char* w = (char*)workspace;
@@ -677,10 +706,10 @@ extern "C" int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uin
 // or below (dir = -1: dz < 0).  `nzone` = the neighbour's H boundary planes nearest to this slab (H >= max |dz|), already as
 // GLOBAL cluster ids (0 = masked out).  Validity = the grid pass's rules (in bounds, stride grid in global coordinates for
 // repulsive edges, both ends unmasked).  Records are appended in no particular order (the second level sorts by wkey, gid).
-__global__ void mws_cross_kernel(const float* w, const long* lab, long base_own, const long* nzone, int H, int Zs, int Y, int X, int z0,
+__global__ void mws_cross_kernel(MwsSrc w, const long* lab, long base_own, const long* nzone, int H, int Zs, int Y, int X, int z0,
                                  long Ng, int dir, const int* offsets, int n_off, int n_attr, int sz, int sy, int sx, int invert, float bias,
                                  unsigned* wkey, u64* gid, long* gu, long* gv, unsigned char* attr, unsigned* count, unsigned cap) {
-  const long plane = (long)Y * X, total = (long)n_off * H * plane, Ns = (long)Zs * plane;
+  const long plane = (long)Y * X, total = (long)n_off * H * plane;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
     const int x = (int)(t % X), y = (int)((t / X) % Y), j = (int)((t / plane) % H), k = (int)(t / (plane * H));
     const int dz = offsets[3 * k], a = dz < 0 ? -dz : dz;
@@ -693,7 +722,7 @@ __global__ void mws_cross_kernel(const float* w, const long* lab, long base_own,
     const long ul = (long)zl * plane + (long)y * X + x;
     const long lu = lab[ul], lv = nzone[(long)zn * plane + (long)y2 * X + x2];
     if (lu <= 0 || lv <= 0) continue;
-    float ww = w[(long)k * Ns + ul];
+    float ww = mws_src(w, k, ul);
     if (k >= n_attr) { if (invert) ww = __fadd_rn(__fmul_rn(ww, -1.f), 1.f); }
     else ww = __fadd_rn(ww, bias);
     const unsigned pos = atomicAdd(count, 1u);
@@ -730,10 +759,29 @@ static int mws_slab_args_ok(const rg_mws_params* p) {
   return p && p->shape[0] > 0 && p->shape[1] > 0 && p->shape[2] > 0 && p->n_offsets > 0 && p->n_offsets <= 64 && p->n_attractive >= 0 &&
          p->n_attractive <= p->n_offsets && p->strides[0] > 0 && p->strides[1] > 0 && p->strides[2] > 0 && p->origin[0] >= 0;
 }
+static int mws_cross_src(MwsSrc weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
+                         int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
+                         int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s);
 extern "C" int rg_mws_cross_edges(const float* weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
                                   int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
                                   int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s) {
-  if (!mws_slab_args_ok(p) || !weights || !labels || !nzone || !offsets || !wkey || !gid || !gu || !gv || !attractive || !count || H <= 0 ||
+  if (!p) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_cross_edges: null parameters");
+  const MwsSrc src = {weights, (long)p->shape[0] * p->shape[1] * p->shape[2], 0.f, 0};
+  return mws_cross_src(src, labels, base_own, nzone, H, dir, n_global_voxels, offsets, p, wkey, gid, gu, gv, attractive, count, cap, s);
+}
+extern "C" int rg_mws_cross_edges_u8(const uint8_t* affs8, float scale, int32_t prepare_sep, int64_t channel_stride, const int64_t* labels,
+                                     int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir, int64_t n_global_voxels, const int32_t* offsets,
+                                     const rg_mws_params* p, uint32_t* wkey, uint64_t* gid, int64_t* gu, int64_t* gv, uint8_t* attractive,
+                                     uint32_t* count, uint32_t cap, rg_stream s) {
+  if (!p || scale == 0.f || prepare_sep < 0 || channel_stride < (int64_t)p->shape[0] * p->shape[1] * p->shape[2])
+    RG_FAIL(RG_ERR_BAD_SHAPE, "mws_cross_edges_u8: bad scale / prepare_sep / channel stride");
+  const MwsSrc src = {affs8, (long)channel_stride, scale, prepare_sep};
+  return mws_cross_src(src, labels, base_own, nzone, H, dir, n_global_voxels, offsets, p, wkey, gid, gu, gv, attractive, count, cap, s);
+}
+static int mws_cross_src(MwsSrc weights, const int64_t* labels, int64_t base_own, const int64_t* nzone, int32_t H, int32_t dir,
+                         int64_t n_global_voxels, const int32_t* offsets, const rg_mws_params* p, uint32_t* wkey, uint64_t* gid,
+                         int64_t* gu, int64_t* gv, uint8_t* attractive, uint32_t* count, uint32_t cap, rg_stream s) {
+  if (!mws_slab_args_ok(p) || !weights.p || !labels || !nzone || !offsets || !wkey || !gid || !gu || !gv || !attractive || !count || H <= 0 ||
       (dir != 1 && dir != -1)) RG_FAIL(RG_ERR_BAD_SHAPE, "mws_cross_edges: bad arguments");
   const long total = (long)p->n_offsets * H * p->shape[1] * p->shape[2];
   int blocks = (int)((total + 255) / 256); if (blocks > 65535) blocks = 65535;

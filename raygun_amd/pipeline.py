@@ -36,11 +36,13 @@ def predict_and_segment(model, volume, input_shape=(196, 196, 196), output_shape
     if affs8.shape[0] != len(nb):
         raise ValueError(f"the model predicts {affs8.shape[0]} affinity channels, the neighbourhood has {len(nb)} offsets")
     S._stage(None, dev)
-    # uint8 destinations hold value * 255: back to [0, 1] inside the kernel (the float32 affinities — 4 bytes per value, 86 GB for a
-    # 2048^3 / 8 part — would exist only to be read once, and allocating them cost more than the whole watershed)
-    w, m = S.prepare_weights_u8(affs8, 1.0 / 255.0, sep, mask_thresh, 1.0, device=dev)
-    S._stage("uint8 -> float + rg_mws_prepare", dev)
-    need = -(-(w.shape[0] * w[0].numel()) // S.SINGLE_PASS_EDGE_IDS)
+    # uint8 destinations hold value * 255: taken back to [0, 1] and through segment.py:188-194 INSIDE the kernels that read them — neither the
+    # float32 affinities nor the float32 weights (4 bytes per value: 87 GB each for a 2048^3 / 8 part) are ever materialised; allocating
+    # them cost more than the whole watershed.  Bit for bit the float route (tests/test_mws.py).
+    _, m = S.prepare_weights_u8(affs8, 1.0 / 255.0, sep, mask_thresh, 1.0, device=dev, mask_only=True)
+    w = S.U8Affinities(affs8, 1.0 / 255.0, sep)
+    S._stage("mask (rg_mws_prepare_u8)", dev)
+    need = -(-(w.shape[0] * affs8[0].numel()) // S.SINGLE_PASS_EDGE_IDS)
     if global_shape is not None or max(need, n_slabs or 1) > 1:
         labels = S.segment_slabs(w, nb, sep, strides=list(strides), mask=m, n_slabs=max(need, n_slabs or 1), device=dev, as_tensor=True,
                                  z0=z0, global_shape=global_shape)

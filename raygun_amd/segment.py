@@ -51,6 +51,26 @@ def build_neighborhood(neighborhood=None, n_diagonals=8):
     return nb
 
 
+class U8Affinities:
+    """The block runner's uint8 affinities (n_offsets, Z, Y, X) on the GPU standing in for the float32 weight array of segment.py:188-199:
+    weights[k] = 1 - u8 * scale, flipped back for k < sep (rg_mws_prepare's arithmetic, applied inside the edge kernels).  Accepted wherever
+    compute_mws_segmentation / segment_slabs take `weights`; Z-slabs are views of `t` (each channel contiguous), never copies."""
+
+    def __init__(self, t, scale, sep):
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.uint8 and t.dim() == 4):
+            raise RuntimeError("raygun_amd.U8Affinities: a (n_offsets, Z, Y, X) uint8 tensor on the MI355X expected")
+        if t.stride(3) != 1 or t.stride(2) != t.shape[3] or t.stride(1) != t.shape[2] * t.shape[3]:
+            t = t.contiguous()
+        self.t, self.scale, self.sep = t, float(np.float32(scale)), int(sep)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def slab(self, z0, z1):
+        return U8Affinities(self.t[:, z0:z1], self.scale, self.sep)
+
+
 def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, strides=None, randomize_strides=False,
                              invert_repulsive_weights=True, bias_cut=0., mask=None, algorithm="kruskal", device=None,
                              as_tensor=False, origin=(0, 0, 0), stats=None):
@@ -76,8 +96,12 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("raygun_amd.compute_mws_segmentation runs on the MI355X only (no CPU fallback)")
-    w = torch.as_tensor(np.ascontiguousarray(weights, dtype=np.float32) if isinstance(weights, np.ndarray) else weights)
-    w = w.to(dev, torch.float32).contiguous()
+    u8 = weights if isinstance(weights, U8Affinities) else None
+    if u8 is not None:
+        w = u8.t
+    else:
+        w = torch.as_tensor(np.ascontiguousarray(weights, dtype=np.float32) if isinstance(weights, np.ndarray) else weights)
+        w = w.to(dev, torch.float32).contiguous()
     if w.dim() != 4 or w.shape[0] != len(offsets):
         raise ValueError(f"weights must be (n_offsets, Z, Y, X); got {tuple(w.shape)} for {len(offsets)} offsets")
     off = torch.as_tensor(np.ascontiguousarray(offsets, dtype=np.int32)).to(dev)
@@ -103,10 +127,16 @@ def compute_mws_segmentation(weights, offsets, number_of_attractive_channels, st
                            "(n_offsets * voxels must stay below 2^32) — use segment_slabs (Z-slabs + one exchange step)")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.rg_mws_segment(C.c_void_p(w.data_ptr()), C.c_void_p(off.data_ptr()),
-                                    C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
-                                    C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
-                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment")
+        if u8 is not None:
+            _lib.check(L.rg_mws_segment_u8(C.c_void_p(w.data_ptr()), u8.scale, u8.sep, int(w.stride(0)), C.c_void_p(off.data_ptr()),
+                                           C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
+                                           C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
+                                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment_u8")
+        else:
+            _lib.check(L.rg_mws_segment(C.c_void_p(w.data_ptr()), C.c_void_p(off.data_ptr()),
+                                        C.c_void_p(m.data_ptr()) if m is not None else None, C.c_void_p(labels.data_ptr()),
+                                        C.byref(p), C.c_void_p(ws.data_ptr()), nbytes,
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_segment")
         if stats is not None:  # diagnostics of the round kernel (synchronises)
             buf = (C.c_uint64 * 8)()
             _lib.check(L.rg_mws_stats(C.c_void_p(ws.data_ptr()), C.byref(p), buf, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_stats")
@@ -141,7 +171,7 @@ def prepare_weights(affs, sep, mask_thresh, max_affinity_value, device=None):
     return w, m
 
 
-def prepare_weights_u8(affs8, scale, sep, mask_thresh, max_affinity_value, device=None):
+def prepare_weights_u8(affs8, scale, sep, mask_thresh, max_affinity_value, device=None, mask_only=False):
     """prepare_weights(affs8.float() * scale, ...) bit for bit, without the float32 affinities: affs8 is the (n_offsets, Z, Y, X) uint8 tensor the
     block runner leaves on the device (worker.py:133-144 stores value * 255 for integer destinations; scale = 1 / 255 takes it back to [0, 1])."""
     dev = torch.device(device if device is not None else "cuda")
@@ -150,11 +180,11 @@ def prepare_weights_u8(affs8, scale, sep, mask_thresh, max_affinity_value, devic
     a = affs8.contiguous()
     if a.dim() != 4:
         raise ValueError(f"affs must be (n_offsets, Z, Y, X); got {tuple(a.shape)}")
-    w = torch.empty(tuple(a.shape), dtype=torch.float32, device=dev)
+    w = None if mask_only else torch.empty(tuple(a.shape), dtype=torch.float32, device=dev)   # mask_only: the weights stay implicit (U8Affinities)
     m = torch.empty(tuple(a.shape[1:]), dtype=torch.uint8, device=dev)
     if m.numel():
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().rg_mws_prepare_u8(C.c_void_p(a.data_ptr()), float(np.float32(scale)), C.c_void_p(w.data_ptr()), C.c_void_p(m.data_ptr()),
+            _lib.check(_lib.lib().rg_mws_prepare_u8(C.c_void_p(a.data_ptr()), float(np.float32(scale)), C.c_void_p(w.data_ptr()) if w is not None else None, C.c_void_p(m.data_ptr()),
                                                     m.numel(), a.shape[0], int(sep), float(np.float32(mask_thresh * max_affinity_value)),
                                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rg_mws_prepare_u8")
     return w, m
@@ -206,7 +236,11 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda":
         raise RuntimeError("raygun_amd.segment_slabs runs on the MI355X only (no CPU fallback)")
-    w = torch.as_tensor(np.ascontiguousarray(weights, dtype=np.float32) if isinstance(weights, np.ndarray) else weights).to(dev, torch.float32).contiguous()
+    u8 = weights if isinstance(weights, U8Affinities) else None
+    if u8 is not None:
+        w = u8.t
+    else:
+        w = torch.as_tensor(np.ascontiguousarray(weights, dtype=np.float32) if isinstance(weights, np.ndarray) else weights).to(dev, torch.float32).contiguous()
     off_np = np.ascontiguousarray(offsets, dtype=np.int32)
     off = torch.as_tensor(off_np).to(dev)
     K, Zl, Y, X = w.shape
@@ -238,7 +272,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     labs, counts = [], []
     for zs, t in mine:
         zl = zs - zbase
-        lab = compute_mws_segmentation(w[:, zl:zl + t], off_np, n_attr, strides, mask=None if m is None else m[zl:zl + t],
+        lab = compute_mws_segmentation(u8.slab(zl, zl + t) if u8 is not None else w[:, zl:zl + t], off_np, n_attr, strides, mask=None if m is None else m[zl:zl + t],
                                        invert_repulsive_weights=invert_repulsive_weights, bias_cut=bias_cut, device=dev,
                                        as_tensor=True, origin=(zs, 0, 0))
         if int(lab.view(-1)[0].item()) == -1:
@@ -280,7 +314,7 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
     for sid, lab, (zs, t) in zip(my_ids, labs, mine):
         zl = zs - zbase
         p = _mws_params((t, Y, X), K, n_attr, strides, invert_repulsive_weights, bias_cut, (zs, 0, 0))
-        wsl = w[:, zl:zl + t].contiguous()
+        wsl = w[:, zl:zl + t] if u8 is not None else w[:, zl:zl + t].contiguous()   # (uint8: addressed in place through its channel stride)
         for d, nz in ((1, nb_above.get(sid)), (-1, nb_below.get(sid))):
             if nz is None or per_dir[d] == 0 or (d == 1 and sid == S - 1) or (d == -1 and sid == 0):
                 continue
@@ -289,10 +323,16 @@ def segment_slabs(weights, offsets, number_of_attractive_channels, strides=None,
             gu = torch.empty(cap, dtype=torch.int64, device=dev); gv = torch.empty(cap, dtype=torch.int64, device=dev)
             at = torch.empty(cap, dtype=torch.uint8, device=dev); cnt = torch.zeros(1, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(L.rg_mws_cross_edges(C.c_void_p(wsl.data_ptr()), C.c_void_p(lab.data_ptr()), int(bases[sid]), C.c_void_p(nz.data_ptr()), H, d, Ng,
-                                                C.c_void_p(off.data_ptr()), C.byref(p), C.c_void_p(wk.data_ptr()), C.c_void_p(gid.data_ptr()),
-                                                C.c_void_p(gu.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(at.data_ptr()), C.c_void_p(cnt.data_ptr()),
-                                                cap, st()), "rg_mws_cross_edges")
+                if u8 is not None:
+                    _lib.check(L.rg_mws_cross_edges_u8(C.c_void_p(wsl.data_ptr()), u8.scale, u8.sep, int(wsl.stride(0)), C.c_void_p(lab.data_ptr()), int(bases[sid]),
+                                                       C.c_void_p(nz.data_ptr()), H, d, Ng, C.c_void_p(off.data_ptr()), C.byref(p), C.c_void_p(wk.data_ptr()),
+                                                       C.c_void_p(gid.data_ptr()), C.c_void_p(gu.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(at.data_ptr()),
+                                                       C.c_void_p(cnt.data_ptr()), cap, st()), "rg_mws_cross_edges_u8")
+                else:
+                    _lib.check(L.rg_mws_cross_edges(C.c_void_p(wsl.data_ptr()), C.c_void_p(lab.data_ptr()), int(bases[sid]), C.c_void_p(nz.data_ptr()), H, d, Ng,
+                                                    C.c_void_p(off.data_ptr()), C.byref(p), C.c_void_p(wk.data_ptr()), C.c_void_p(gid.data_ptr()),
+                                                    C.c_void_p(gu.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(at.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                    cap, st()), "rg_mws_cross_edges")
             n = int(cnt.item())
             if n > cap:
                 raise RuntimeError("raygun_amd.segment_slabs: cross-edge capacity exceeded (internal error)")

@@ -146,6 +146,37 @@ def test_gpu_prepare_from_uint8_bit_exact():
 
 
 @pytest.mark.gpu
+def test_gpu_segment_from_uint8_affinities_equals_the_float_route():
+    """U8Affinities (rg_mws_segment_u8 / rg_mws_cross_edges_u8: the preprocessing of segment.py:188-194 applied inside the edge kernels, slabs addressed
+    in place) gives the labels of the float route — rg_mws_prepare_u8's weights through rg_mws_segment — bit for bit: one pass, forced Z-slabs,
+    and against the CPU oracle on the oracle's own prepare() of the same values.  uint8 values tie constantly: the tie order is exercised too."""
+    import torch
+    from raygun_amd.segment import (U8Affinities, build_neighborhood, compute_mws_segmentation, prepare_weights_u8, segment_slabs)
+    nb = build_neighborhood(None, 8)
+    shape = (30, 26, 34)
+    rng = np.random.default_rng(12)
+    zz, yy, xx = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    blobs = (np.sin(zz / 3.1) * np.sin(yy / 2.7 + 1) * np.sin(xx / 3.3) > -0.2)
+    a8 = np.stack([np.where(blobs, 200, 30) + rng.integers(-25, 26, size=shape) for _ in range(len(nb))]).clip(0, 255).astype(np.uint8)
+    t8 = torch.from_numpy(a8).cuda()
+    scale = np.float32(1.0 / 255.0)
+    w, m = prepare_weights_u8(t8, float(scale), 3, 0.5, 1.0)
+    _, m2 = prepare_weights_u8(t8, float(scale), 3, 0.5, 1.0, mask_only=True)
+    assert torch.equal(m, m2)
+    src = U8Affinities(t8, float(scale), 3)
+    ref = compute_mws_segmentation(w, nb, 3, [3, 3, 3], mask=m)
+    got = compute_mws_segmentation(src, nb, 3, [3, 3, 3], mask=m)
+    assert got.dtype == np.uint64 and (got == ref).all()
+    ww, mm = O.prepare(a8.astype(np.float32) * scale, 3, 0.5, 1.0)
+    assert (got == O.compute_mws_segmentation(ww, nb, 3, [3, 3, 3], mm)).all()
+    ref_s = segment_slabs(w, nb, 3, strides=[3, 3, 3], mask=m, n_slabs=3)
+    got_s = segment_slabs(src, nb, 3, strides=[3, 3, 3], mask=m, n_slabs=3)
+    assert (got_s == ref_s).all() and got_s.max() > 3
+    with pytest.raises(RuntimeError):
+        U8Affinities(torch.from_numpy(a8), float(scale), 3)          # host tensor
+
+
+@pytest.mark.gpu
 def test_gpu_ties_and_empty():
     from raygun_amd.segment import compute_mws_segmentation
     # every weight equal: the tie order (ascending edge id) decides everything
