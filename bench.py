@@ -577,6 +577,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
                step_frac_of_mfma_peak=round(flop / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
                host_enqueue_ms_per_step=round(t_enq / steps * 1e3, 3),
                step_ms_each=[round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(steps)],
+               ms_per_step_median=round(sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(steps))[steps // 2], 3),
                **(dict(optimizer_ms=round(sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3),
                        fwd_bwd_ms=round(ms - sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3)) if opt_marks else {}),
                executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -624,9 +625,9 @@ def main():
         # the same run, after the U-Net's memory is released, and reported inside the same JSON line
         import gc
         gc.collect(); torch.cuda.empty_cache()
-        sec = run_train(a, "cyclegan", 128, max(3, a.steps // 2), max(3, a.warmup), rank, world, dev)
+        sec = run_train(a, "cyclegan", 128, max(3, a.steps), max(3, a.warmup), rank, world, dev)   # >= 20 steps after 5 warm-up
         if res is not None and sec is not None:
-            res["secondary"] = dict(metric=sec["metric"], value=sec["value"], unit=sec["unit"], ms_per_step=sec["ms_per_step"],
+            res["secondary"] = dict(metric=sec["metric"], value=sec["value"], unit=sec["unit"], ms_per_step=sec["ms_per_step"], ms_per_step_median=sec["ms_per_step_median"],
                                     steps=sec["steps"], warmup=sec["warmup"], higher_is_better=False, config=sec["config"],
                                     algorithmic_tflop_per_step=sec["algorithmic_tflop_per_step"], executed_tflop_per_step=sec["executed_tflop_per_step"],
                                     algorithmic_tflops=sec["step_tflops"], executed_tflops=sec["executed_tflops"],
