@@ -69,6 +69,12 @@ int32_t rg_get_option(const char* name);   /* -1: unknown name */
  * [C,dst_lanes) of dst are zero-filled (dst channel stride must be 1 when dst_lanes > C).
  * y = x*scale + shift fuses the block-runner normalisation (worker.py:109-114). */
 int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, rg_stream s);
+/* the block runner's write-back (worker.py:133-149) in one pass: the network's channels-last output straight into the ROI of the destination array —
+ * dst may also be u8: y = (uint8) clamp(x * scale + shift, lo, hi), truncated like the reference's `(out * iinfo.max).clip(...).astype(dtype)` —
+ * and *nonfinite_flag (optional, float, never cleared here) = 1 when a source value is inf / NaN (IEEE-half storage overflows at 65504: such a
+ * block is predicted again with bf16 storage). */
+int rg_copy_convert_store(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, float lo, float hi,
+                          float* nonfinite_flag, rg_stream s);
 
 /* ---- weight packing.  w is the fp32 master in torch layout:
  *   transposed == 0 : Conv3d weight (Cout,Cin,KD,KH,KW)        [torch.nn.Conv3d, networks/UNet.py:58-69]

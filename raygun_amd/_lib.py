@@ -50,6 +50,7 @@ _SIGS = {
     "rg_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "rg_get_option": (C.c_int32, [C.c_char_p]),
     "rg_copy_convert": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "rg_copy_convert_store": (C.c_int, [_T, _T, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rg_nonfinite_check": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rg_conv3d_kalign": (C.c_int, [C.c_int, C.c_int]),
     "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),

@@ -105,7 +105,10 @@ __device__ __forceinline__ float load_any(const AnyT& t, long off) {
     default: return bf2f(((const bf16_t*)t.p)[off]);
   }
 }
-__global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int H, int W, int lanes, float scale, float shift) {
+// `sat` (uint8 destinations — the block runner's integer outputs, worker.py:133-144): the value is clamped to [lo, hi] and truncated like
+// numpy's / torch's float -> uint8 cast.  `flag` (optional): set to 1 when a SOURCE value is inf / NaN (never cleared here).
+__global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int H, int W, int lanes, float scale, float shift, float lo, float hi,
+                                    float* flag) {
   const int G8 = (lanes + 7) / 8;
   const long nvox = (long)N * D * H * W, total = nvox * G8;
   // the channels-last side (bf16, channel stride 1, 16-byte voxel granules) moves as ONE 16-byte access per thread; the dense
@@ -131,17 +134,21 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
       dof = n * dst.s[0] + d * dst.s[2] + h * dst.s[3] + w * dst.s[4];
     }
     float val[8];
+    bool bad = false;
     if (src_cl && grp * 8 + 8 <= C && (((unsigned long)((const bf16_t*)src.p + so + grp * 8)) & 15) == 0) {
       const bf16x8 raw = *(const bf16x8*)((const bf16_t*)src.p + so + grp * 8);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) val[k] = bf2f((bf16_t)raw[k]) * scale + shift;
+      for (int k = 0; k < 8; ++k) { const float x = bf2f((bf16_t)raw[k]); bad |= (x - x) != 0.f; val[k] = x * scale + shift; }
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int c = grp * 8 + k;
-        val[k] = c < C ? load_any(src, so + c * src.s[1]) * scale + shift : 0.f;
+        const float x = c < C ? load_any(src, so + c * src.s[1]) : 0.f;
+        bad |= (x - x) != 0.f;
+        val[k] = c < C ? x * scale + shift : 0.f;
       }
     }
+    if (flag && bad) *flag = 1.f;
     if (dst_cl) {
       bf16x8 o;
 #pragma unroll
@@ -153,6 +160,7 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
         const int c = grp * 8 + k;
         if (c >= lanes) break;
         if (dst.dtype == RG_F32) ((float*)dst.p)[dof + c * dst.s[1]] = val[k];
+        else if (dst.dtype == RG_U8) ((unsigned char*)dst.p)[dof + c * dst.s[1]] = (unsigned char)(int)fminf(fmaxf(val[k], lo), hi);
         else ((bf16_t*)dst.p)[dof + c * dst.s[1]] = f2bf(val[k]);
       }
     }
@@ -160,10 +168,15 @@ __global__ void copy_convert_kernel(AnyT src, AnyT dst, int N, int C, int D, int
 }
 
 extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, rg_stream s) {
+  return rg_copy_convert_store(src, dst, dst_lanes, scale, shift, 0.f, 255.f, nullptr, s);
+}
+extern "C" int rg_copy_convert_store(const rg_tensor* src, const rg_tensor* dst, int dst_lanes, float scale, float shift, float lo, float hi,
+                                     float* nonfinite_flag, rg_stream s) {
   if (!src || !dst || !src->ptr || !dst->ptr) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: null tensor");
   if (src->rank != 5 || dst->rank != 5) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: rank-5 tensors expected");
   for (int i = 0; i < 5; ++i) if (src->sizes[i] != dst->sizes[i]) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: shape mismatch on dim %d", i);
-  if (dst->dtype != RG_ACT_DTYPE && dst->dtype != RG_F32) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: dst must be this build's 16-bit type or f32");
+  if (dst->dtype != RG_ACT_DTYPE && dst->dtype != RG_F32 && dst->dtype != RG_U8) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: dst must be this build's 16-bit type, f32 or u8");
+  if (dst->dtype == RG_U8 && (lo < 0.f || hi > 255.f || !(lo <= hi))) RG_FAIL(RG_ERR_BAD_SHAPE, "copy_convert: u8 saturation bounds");
   if (src->dtype != RG_ACT_DTYPE && src->dtype != RG_F32 && src->dtype != RG_U8) RG_FAIL(RG_ERR_UNSUPPORTED, "copy_convert: src dtype");
   const int C = (int)src->sizes[1];
   if (dst_lanes < C) dst_lanes = C;
@@ -174,7 +187,7 @@ extern "C" int rg_copy_convert(const rg_tensor* src, const rg_tensor* dst, int d
   const long total = (long)src->sizes[0] * src->sizes[2] * src->sizes[3] * src->sizes[4] * ((dst_lanes + 7) / 8);
   if (total == 0) return RG_OK;
   hipLaunchKernelGGL(copy_convert_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, a, b, (int)src->sizes[0], C,
-                     (int)src->sizes[2], (int)src->sizes[3], (int)src->sizes[4], dst_lanes, scale, shift);
+                     (int)src->sizes[2], (int)src->sizes[3], (int)src->sizes[4], dst_lanes, scale, shift, lo, hi, nonfinite_flag);
   RG_CHECK_LAUNCH();
   return RG_OK;
 }

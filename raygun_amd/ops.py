@@ -228,6 +228,18 @@ class _FromCL(Function):
         return to_cl(g)
 
 
+def store_block(t, dst, scale=1.0, lo=0.0, hi=255.0, flag=None):
+    """The block runner's write-back in one kernel (rg_copy_convert_store): channels-last 16-bit `t` (N,C,D,H,W — any crop view) into `dst`, a
+    same-shaped view of the destination array (float32, or uint8: clamp(t * scale, lo, hi) truncated); `flag` (float32[1]) is set when `t`
+    holds an inf / NaN."""
+    if t.numel() == 0:
+        return
+    if tuple(t.shape) != tuple(dst.shape) or dst.dtype not in (torch.float32, torch.uint8) or t.dtype not in _KIND:
+        raise RuntimeError(f"raygun_amd.store_block: {tuple(t.shape)} {t.dtype} -> {tuple(dst.shape)} {dst.dtype}")
+    _lib.check(_lib.lib(_KIND[t.dtype]).rg_copy_convert_store(C.byref(desc(t)), C.byref(desc(dst)), t.shape[1], float(scale), 0.0, float(lo), float(hi),
+                                                              C.c_void_p(flag.data_ptr()) if flag is not None else None, _stream()), "rg_copy_convert_store")
+
+
 _lift = threading.local()  # .on: a 4-D (N,C,H,W) tensor entered the current outermost scope and was lifted to D = 1
 
 

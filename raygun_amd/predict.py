@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import hipnn, ops, parallel
 
 
 def roi_geometry(ndims=3, input_shape=None, output_shape=None, read_size=None, crop=0, voxel_size=(1, 1, 1)):
@@ -140,7 +140,8 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         if blk.dtype not in (torch.uint8,):
             blk = blk.float()
         x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
-        outs = model(x)
+        with hipnn.scope():               # an enclosing scope: a raygun_amd network hands its outputs over channels-last, 16-bit (no fp32 copy)
+            outs = model(x)
         if not isinstance(outs, (tuple, list)):
             outs = (outs,)
         if state["destinations"] is None:
@@ -154,7 +155,35 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         dests = state["destinations"]
         out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in dests}
         finite = None
+        flag = None
         for o, dest in zip(outs, dests):
+            odt = np.dtype(out_dt[id(dest)])
+            if ops.is_cl(o) and o.dim() == 5 and o.shape[0] == 1 and not ops.lifted() and odt in (np.dtype(np.uint8), np.dtype(np.float32)):
+                # one kernel: crop view -> [* 255, clamp, truncate] -> the ROI of the destination, with the inf / NaN check (worker.py:133-149)
+                o = o.detach()
+                if crop and crop != 0 and input_shape is None:
+                    o = o[..., crop:-crop, crop:-crop, crop:-crop]
+                if tuple(o.shape[-3:]) != tuple(write):
+                    off = [(a - b) // 2 for a, b in zip(o.shape[-3:], write)]
+                    o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
+                if flag is None:
+                    flag = torch.zeros(1, dtype=torch.float32, device=dev)
+                roi = (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2]))
+                if resident:
+                    tgt = dest[roi]
+                else:
+                    tgt = torch.empty(((o.shape[1],) if dest.ndim == 4 else ()) + tuple(write), dtype=_TORCH_DT[odt], device=dev)
+                view = tgt if tgt.dim() == 4 else tgt[None]
+                if view.shape[0] != o.shape[1]:
+                    raise ValueError(f"destination {tuple(dest.shape)} does not match the network's {o.shape[1]} output channels")
+                isint = odt == np.dtype(np.uint8)
+                ops.store_block(o, view[None], 255.0 if isint else 1.0, 0.0, 255.0, flag)
+                if not resident:
+                    if state["drain"] is None:
+                        state["drain"] = _Drain(dev)
+                    state["drain"].put(tgt, dest, roi)
+                continue
+            o = ops.leave(o) if ops.is_cl(o) else o
             o = o.detach().float()[0]
             if crop and crop != 0 and input_shape is None:
                 o = o[..., crop:-crop, crop:-crop, crop:-crop]
@@ -172,6 +201,9 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                     state["drain"] = _Drain(dev)
                 state["drain"].put(_to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True).contiguous(), dest,
                                    (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2])))
+        if flag is not None:
+            f = (flag == 0)[0]
+            finite = f if finite is None else finite & f
         return finite
 
     try:
