@@ -152,6 +152,36 @@ def test_train_checkpoint_predict_round_trip(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_train_f16_precision_with_loss_scaling_through_the_entry_point(tmp_path, monkeypatch):
+    """raygun-train on a config with "precision": "f16" (+ "loss_scale_kwargs"): the Trainer wraps forward + loss in IEEE-half storage, scales the
+    loss, FusedAdam steps with 1/scale folded in; the checkpoint carries the scaler; a resumed system restores it.  An initial scale far beyond
+    half's range must be backed off (skipped steps) until the step applies."""
+    from raygun_amd.load_system import load_system
+    from raygun_amd.train import train
+    monkeypatch.chdir(tmp_path)
+    conf = _train_conf(tmp_path, precision="f16", loss_scale_kwargs={"init_scale": 2.0 ** 14, "growth_interval": 2},
+                       train_kwargs={"checkpoint_basename": "./models/model", "num_epochs": 4, "save_every": 4, "log_every": 1})
+    loss, outs = train(conf)
+    assert torch.isfinite(loss) and outs["pred_affs"].dtype == torch.float32
+    ck = torch.load(str(tmp_path / "models" / "model_checkpoint_4"), weights_only=False)
+    assert ck["iteration"] == 4 and ck["loss_scaler"]["skipped"] == 0
+    assert ck["loss_scaler"]["scale"] == 2.0 ** 16                      # doubled after every 2 clean steps
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 4.0
+    s = load_system(conf)
+    s.build_system()
+    assert s.trainer.scaler is not None and s.trainer.scaler.scale_value == 2.0 ** 16 and s.trainer.iteration == 4
+    # a scale that overflows half: backed off step by step, Adam's step count only advances when a step is applied
+    d2 = tmp_path / "big"; d2.mkdir(); monkeypatch.chdir(d2)
+    conf2 = _train_conf(d2, precision="f16", loss_scale_kwargs={"init_scale": 2.0 ** 40, "max_scale": 2.0 ** 41, "growth_interval": 1000},
+                        train_kwargs={"checkpoint_basename": "./models/model", "num_epochs": 30, "save_every": 30, "log_every": 1})
+    train(conf2)
+    ck2 = torch.load(str(d2 / "models" / "model_checkpoint_30"), weights_only=False)
+    sk = ck2["loss_scaler"]["skipped"]
+    assert 1 <= sk < 30 and ck2["loss_scaler"]["scale"] == 2.0 ** (40 - sk)
+    assert float(ck2["optimizer_state_dict"]["state"][0]["step"]) == 30 - sk
+
+
+@pytest.mark.gpu
 def test_train_mtlsd_from_label_sources(tmp_path, monkeypatch):
     """raygun-train on an MTLSD config WITH `sources` (label volumes) and no "synthetic_data": the batches come from
     MTLSDCropBatches — random crops + GPU-generated LSDs / affinities / balance weights (reference flow
