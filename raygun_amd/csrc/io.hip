@@ -2,7 +2,12 @@
 // Blosc compressor (cname "lz4" / "lz4hc").  Restated from the published LZ4 block format description (lz4_Block_format.md):
 // a block is a series of sequences [token][literal length+][literals][offset LE16][match length+]; the last sequence ends after
 // its literals.  No device code here; it lives in the library so that the Python reader has a native path for multi-megabyte chunks.
+#ifdef RG_IO_STANDALONE   // tests/test_oracle_sanitize.py builds this file alone with g++ -fsanitize=address,undefined (no HIP headers needed: host code only)
+#include <stdint.h>
+#include <string.h>
+#else
 #include "common.h"
+#endif
 
 // returns the number of bytes written to dst, or -1 on malformed input / overflow of either buffer
 extern "C" int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
