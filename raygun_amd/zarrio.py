@@ -14,7 +14,7 @@ when the library is not built; blosclz / zstd / snappy inner codecs raise) and W
 against numcodecs' Blosc as well: the tests decode frames laid down by hand from the format description.
 Filters are not supported.  N5 containers (the other format daisy.open_ds accepts) are READ through `N5Array`: attributes.json
 (dimensions / blockSize / dataType / compression, all in N5's fastest-axis-first order, reversed here), big-endian block files
-i0/i1/.. with the [mode, ndim, dims..] header, compression raw / gzip / bzip2 / xz / blosc; restated from the published N5 spec,
+i0/i1/.. with the [mode, ndim, dims..] header, compression raw / gzip / bzip2 / xz / blosc, read AND written; restated from the published N5 spec,
 unpinned like the rest.
 """
 import builtins
@@ -215,9 +215,19 @@ class _ChunkLock:
     def __init__(self, chunk_path):
         import hashlib
         root = os.path.dirname(chunk_path)
-        while root and not os.path.exists(os.path.join(root, ".zarray")):
-            root = os.path.dirname(root)
-        d = os.path.join(root or os.path.dirname(chunk_path), ".locks")
+        found = None
+        for _ in range(64):   # the dataset directory: zarr's holds .zarray; an N5 dataset's attributes.json lies up to ndim levels above its blocks
+            if os.path.exists(os.path.join(root, ".zarray")):
+                found = root
+                break
+            if os.path.exists(os.path.join(root, "attributes.json")) and found is None:
+                found = root
+                break
+            up = os.path.dirname(root)
+            if not up or up == root:
+                break
+            root = up
+        d = os.path.join(found or os.path.dirname(chunk_path), ".locks")
         os.makedirs(d, exist_ok=True)
         self.path = os.path.join(d, hashlib.sha1(chunk_path.encode()).hexdigest()[:16])
 
@@ -424,10 +434,11 @@ class Group:
 
 
 class N5Array(Array):
-    """Read-only view of one N5 dataset directory with numpy (slowest-axis-first) semantics."""
+    """One N5 dataset directory with numpy (slowest-axis-first) semantics; writable when opened with mode "r+" / "a" (blocks are written in
+    N5's default mode 0, edge blocks cropped, big-endian, with the dataset's own compression — raw / gzip / bzip2 / xz / blosc)."""
 
-    def __init__(self, path):
-        self.path, self.mode = path, "r"
+    def __init__(self, path, mode="r"):
+        self.path, self.mode = path, mode
         with _fopen(os.path.join(path, "attributes.json")) as f:
             m = json.load(f)
         if "dimensions" not in m:
@@ -442,7 +453,12 @@ class N5Array(Array):
         if comp.get("type") not in dec:
             raise NotImplementedError(f"{path}: N5 compression {comp.get('type')!r} is not supported (raw, gzip, bzip2, xz, blosc are)")
         self._decode = dec[comp["type"]]
-        self.attrs = Attributes(os.path.join(path, "attributes.json"), False)
+        lvl = comp.get("level", -1)
+        self._encode = {"raw": lambda b: b, "gzip": lambda b: gzip.compress(b, 6 if lvl in (-1, None) else int(lvl)),
+                        "bzip2": lambda b: bz2.compress(b, int(comp.get("blockSize", 9))), "xz": lambda b: lzma.compress(b, preset=int(comp.get("preset", 6))),
+                        "blosc": lambda b: blosc_encode(b, {"clevel": comp.get("clevel", 5), "shuffle": comp.get("shuffle", 1), "blocksize": comp.get("blocksize", 0),
+                                                            "_typesize": self.dtype.itemsize})}[comp["type"]]
+        self.attrs = Attributes(os.path.join(path, "attributes.json"), mode != "r")
         self.ndim = len(self.shape)
 
     def _chunk_path(self, idx):
@@ -473,15 +489,50 @@ class N5Array(Array):
     def __getitem__(self, key):
         return super().__getitem__(key).astype(self.dtype.newbyteorder("="), copy=False)
 
+    def _write_chunk(self, idx, data):
+        p = self._chunk_path(idx)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        dims = tuple(min(c, s - i * c) for c, s, i in zip(self.chunks, self.shape, idx))          # edge blocks are stored cropped
+        blk = np.ascontiguousarray(np.asarray(data)[tuple(slice(0, n) for n in dims)], dtype=self.dtype)   # big-endian, slowest axis first
+        head = (0).to_bytes(2, "big") + self.ndim.to_bytes(2, "big") + b"".join(int(n).to_bytes(4, "big") for n in reversed(dims))
+        tmp = p + f".{os.getpid()}.tmp"
+        with _fopen(tmp, "wb") as f:
+            f.write(head + self._encode(blk.tobytes()))
+        os.replace(tmp, p)
+
     def __setitem__(self, key, value):
-        raise NotImplementedError("N5 containers are read-only here: write predictions to a zarr container")
+        if self.mode == "r":
+            raise PermissionError(f"{self.path}: opened read-only")
+        super().__setitem__(key, value)
 
 
-def _open_n5(path, ds_name=None):
+def _open_n5(path, ds_name=None, mode="r"):
     full = os.path.join(path, ds_name) if ds_name else path
     if not os.path.exists(os.path.join(full, "attributes.json")):
         raise FileNotFoundError(os.path.join(full, "attributes.json"))
-    return N5Array(full)
+    return N5Array(full, mode)
+
+
+_N5_TYPES = {"uint8", "uint16", "uint32", "uint64", "int8", "int16", "int32", "int64", "float32", "float64"}
+
+
+def _create_n5(path, ds_name, shape, chunks, dtype, compression=None, overwrite=True):
+    """A fresh N5 dataset: attributes.json in N5's fastest-axis-first order (N5 spec 2.0: dimensions, blockSize, dataType, compression) and
+    {"n5": "2.0.0"} at the container root."""
+    dt = np.dtype(dtype).name
+    if dt not in _N5_TYPES:
+        raise ValueError(f"N5 has no data type {dt!r}")
+    os.makedirs(path, exist_ok=True)
+    root_attr = os.path.join(path, "attributes.json")
+    if not os.path.exists(root_attr):
+        _write_json(root_attr, {"n5": "2.0.0"})
+    full = os.path.join(path, ds_name)
+    if os.path.exists(full) and overwrite:
+        shutil.rmtree(full)
+    os.makedirs(full, exist_ok=True)
+    _write_json(os.path.join(full, "attributes.json"), {"dimensions": [int(v) for v in reversed(shape)], "blockSize": [int(v) for v in reversed(chunks)],
+                                                        "dataType": dt, "compression": compression or {"type": "gzip", "level": -1}})
+    return N5Array(full, "r+")
 
 
 def open(path, mode="r"):  # noqa: A001  (mirrors zarr.open)
@@ -506,7 +557,7 @@ def open_ds(filename, ds_name, mode="r"):
     """daisy.open_ds for zarr containers: the Array, with `.voxel_size` and `.offset` (world units) from its attributes
     ('resolution' / 'offset', defaults 1 and 0 per spatial axis)."""
     if str(filename).rstrip("/").endswith(".n5"):  # daisy reverses N5's (x, y, z) attribute order as well
-        a = _open_n5(filename, ds_name)
+        a = _open_n5(filename, ds_name, mode)
         nsp = min(3, a.ndim)
         a.voxel_size = tuple(int(v) for v in reversed(a.attrs.get("resolution", (1,) * nsp)))
         a.offset = tuple(int(v) for v in reversed(a.attrs.get("offset", (0,) * nsp)))
@@ -522,11 +573,18 @@ def prepare_ds(filename, ds_name, total_shape, voxel_size, dtype, write_size=Non
                compressor="default"):
     """daisy.prepare_ds (predict.py:111-125): a fresh dataset covering `total_shape` voxels (+ a leading channel axis when
     num_channels is given), chunked by the write ROI, carrying 'resolution' and 'offset' attributes."""
-    g = open(filename, "a")
     shape = tuple(int(v) for v in total_shape)
     chunks = tuple(int(v) for v in (write_size if write_size is not None else [min(s, 64) for s in shape]))
     if num_channels is not None:
         shape, chunks = (int(num_channels),) + shape, (int(num_channels),) + chunks
+    if str(filename).rstrip("/").endswith(".n5"):   # an N5 container (the reference's file names end in .n5 or .zarr: predict.py:104-125)
+        comp = None if compressor == "default" else ({"type": "raw"} if compressor is None else compressor)
+        a = _create_n5(str(filename), ds_name, shape, chunks, dtype, comp, overwrite=delete)
+        off = [int(v) for v in (offset if offset is not None else (0,) * len(voxel_size))]
+        a.attrs.update({"resolution": [int(v) for v in reversed(voxel_size)], "offset": list(reversed(off))})     # (x, y, z) like daisy writes them
+        a.voxel_size, a.offset = tuple(int(v) for v in voxel_size), tuple(off)
+        return a
+    g = open(filename, "a")
     a = g.create_dataset(ds_name, shape, chunks=chunks, dtype=dtype, compressor=compressor, overwrite=delete)
     a.attrs.update({"resolution": [int(v) for v in voxel_size], "offset": [int(v) for v in (offset if offset is not None else (0,) * len(voxel_size))]})
     a.voxel_size, a.offset = tuple(int(v) for v in voxel_size), tuple(a.attrs["offset"])

@@ -234,7 +234,7 @@ def test_n5_dataset_laid_down_by_hand(tmp_path):
         got = a[...]
         assert got.dtype == np.uint16 and np.array_equal(got, want)
         assert np.array_equal(a[1:4, 2:5, 3:7], want[1:4, 2:5, 3:7])
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(PermissionError):
             a[0, 0, 0] = 1
 
 
@@ -271,3 +271,38 @@ def test_blosc_encode_frames(tmp_path, dtype, cfg):
     assert np.array_equal(zarrio.open(root)[...], vol)
     raw = open(os.path.join(root, "0.0.0"), "rb").read()
     assert raw[0] == 2 and int.from_bytes(raw[4:8], "little") == 4 * 20 * 16 * ts       # a Blosc frame of one whole chunk
+
+
+@pytest.mark.parametrize("comp", ["default", None, {"type": "bzip2", "blockSize": 9}, {"type": "xz", "preset": 6}, {"type": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}])
+def test_n5_write_round_trip_and_block_layout(tmp_path, comp):
+    """Writing N5 (the reference's containers end in .n5 or .zarr): prepare_ds on a .n5 path lays down attributes.json in N5's (x, y, z) order with the
+    resolution / offset attributes reversed like daisy's, region writes produce mode-0 blocks — header [0, ndim, dims fastest-first], big-endian payload,
+    edge blocks cropped — that the hand-written reader of test_n5_dataset_laid_down_by_hand's format decodes, and open_ds reads the volume back."""
+    import bz2, gzip, lzma
+    root = str(tmp_path / "out.n5")
+    a = zarrio.prepare_ds(root, "volumes/pred", (10, 12, 14), (4, 4, 8), np.float32, write_size=(4, 5, 6), num_channels=3, offset=(40, 0, 16), compressor=comp)
+    meta = json.load(open(os.path.join(root, "volumes/pred", "attributes.json")))
+    assert json.load(open(os.path.join(root, "attributes.json")))["n5"] == "2.0.0"
+    assert meta["dimensions"] == [14, 12, 10, 3] and meta["blockSize"] == [6, 5, 4, 3] and meta["dataType"] == "float32"
+    assert meta["resolution"] == [8, 4, 4] and meta["offset"] == [16, 0, 40]
+    assert a.shape == (3, 10, 12, 14) and a.chunks == (3, 4, 5, 6) and a.voxel_size == (4, 4, 8) and a.offset == (40, 0, 16)
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((3, 10, 12, 14)).astype(np.float32)
+    a[:, 0:4] = vol[:, 0:4]
+    a[:, 4:10, 0:7] = vol[:, 4:10, 0:7]                    # partial blocks: read-modify-write
+    a[:, 4:10, 7:12] = vol[:, 4:10, 7:12]
+    b = zarrio.open_ds(root, "volumes/pred")
+    assert b.voxel_size == (4, 4, 8) and b.offset == (40, 0, 16) and b.dtype.kind == "f"
+    assert np.array_equal(b[...], vol)
+    with pytest.raises(PermissionError):
+        b[0, 0, 0, 0] = 1.0
+    # the last block along every spatial axis, decoded by hand: idx (c=0, z=2, y=2, x=2) -> path x/y/z/c, dims cropped to (3, 2, 2, 2)
+    raw = open(os.path.join(root, "volumes/pred", "2", "2", "2", "0"), "rb").read()
+    assert int.from_bytes(raw[0:2], "big") == 0 and int.from_bytes(raw[2:4], "big") == 4
+    dims = [int.from_bytes(raw[4 + 4 * i:8 + 4 * i], "big") for i in range(4)]
+    assert dims == [2, 2, 2, 3]
+    kind = (meta["compression"] or {}).get("type")
+    dec = {"raw": lambda x: x, "gzip": gzip.decompress, "bzip2": bz2.decompress, "xz": lzma.decompress, "blosc": zarrio.blosc_decode}[kind]
+    blk = np.frombuffer(dec(raw[20:]), dtype=">f4").reshape(3, 2, 2, 2)
+    assert np.array_equal(blk, vol[:, 8:10, 10:12, 12:14])
+    assert kind == ("gzip" if comp == "default" else "raw" if comp is None else comp["type"])
