@@ -35,13 +35,15 @@ class RaygunSequential(hipnn.FusedSequential):
         if not isinstance(inner, hipnn.FusedSequential) or len(inner) == 0:
             return None
         a, b = inner[-1], mods[1]
-        if not isinstance(a, hipnn.Conv3d) or not isinstance(b, hipnn.Conv3d):
+        both3 = isinstance(a, hipnn.Conv3d) and isinstance(b, hipnn.Conv3d)
+        both2 = isinstance(a, hipnn.Conv2d) and isinstance(b, hipnn.Conv2d)     # the 2-D generators (ResNet.py:6-223): a (1, KH, KW) kernel
+        if not (both3 or both2):
             return None
-        if tuple(b.kernel_size) != (1, 1, 1) or tuple(b.stride) != (1, 1, 1) or tuple(a.stride) != (1, 1, 1):
+        if any(k != 1 for k in b.kernel_size) or any(v != 1 for v in b.stride) or any(v != 1 for v in a.stride):
             return None
         if a.padding_mode != "zeros" or a.groups != 1 or b.groups != 1 or any(d != 1 for d in a.dilation):
             return None
-        if b.out_channels * a.kernel_size[2] * 2 > a.out_channels:  # only when the composed map is much thinner
+        if b.out_channels * a.kernel_size[-1] * 2 > a.out_channels:  # only when the composed map is much thinner
             return None
         return inner, a, b
 
@@ -53,7 +55,11 @@ class RaygunSequential(hipnn.FusedSequential):
         mods = list(self)
         x = inner.run(ops.enter(x), upto=len(inner) - 1)
         act = hipnn.act_of(mods[2]) if len(mods) > 2 else None
-        x = ops.conv3d_linear_pair(x, a.weight, a.bias, b.weight, b.bias, a._pads(), *(act if act is not None else ("none", 0.0)))
+        if isinstance(a, hipnn.Conv2d):
+            x = ops.conv3d_linear_pair(x, a.weight.unsqueeze(2), a.bias, b.weight.unsqueeze(2), b.bias, (0,) + tuple(a._pads()),
+                                       *(act if act is not None else ("none", 0.0)))
+        else:
+            x = ops.conv3d_linear_pair(x, a.weight, a.bias, b.weight, b.bias, a._pads(), *(act if act is not None else ("none", 0.0)))
         rest = mods[3:] if act is not None else mods[2:]
         for m in rest:
             x = m(x)

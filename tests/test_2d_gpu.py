@@ -95,6 +95,49 @@ def test_networks_2d_structure_and_forward():
         assert rel <= 3e-2, rel
 
 
+def test_generator_tail_2d_is_composed_like_the_3d_one(monkeypatch):
+    """get_network's Sequential(ResnetGenerator2D[..., Conv2d(ngf, ngf, 7)], Conv2d(ngf, 1, 1)[, Tanh]) (BaseSystem.py:209-224, ResNet.py:6-223):
+    the last two layers run as ONE composed convolution on the 2-D path too (ops.conv3d_linear_pair with a (1, 7, 7) kernel) — same parameters
+    and state_dict; outputs and every parameter's gradient against the layer-by-layer evaluation (RAYGUN_AMD_FUSE_TAIL=0) and the CPU oracle."""
+    import functools
+    from oracle import torch_ref as O
+    from raygun_amd.torch import networks
+    from raygun_amd.torch.systems.BaseSystem import RaygunSequential
+    from raygun_amd import hipnn
+    IN2 = functools.partial(nn.InstanceNorm2d)
+    dev = torch.device("cuda")
+    kw = dict(input_nc=1, ngf=16, n_blocks=2, n_downsampling=1, norm_layer=IN2, padding_type="reflect")
+    go = nn.Sequential(O.ResNet(2, **kw), nn.Conv2d(16, 1, 1), nn.Tanh())
+    sd = synth.fill_state_dict(go.state_dict(), 77)
+    go.load_state_dict(sd)
+    x = torch.from_numpy(synth.uniform((1, 1, 40, 44), 6))
+    gy = torch.from_numpy(synth.uniform((1, 1, 40, 44), 8))
+    yo = go(x); yo.backward(gy)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("RAYGUN_AMD_FUSE_TAIL", fuse)
+        g = RaygunSequential(networks.ResNet(2, **kw), hipnn.Conv2d(16, 1, 1), hipnn.Tanh())
+        assert list(g.state_dict()) == list(go.state_dict())
+        g.load_state_dict(sd); g.to(dev)
+        assert (g._linear_tail() is not None) == (fuse == "1")
+        y = g(x.to(dev)); y.backward(gy.to(dev))
+        res[fuse] = (y.detach().cpu(), {k: p.grad.detach().cpu() for k, p in g.named_parameters()})
+    names = [k for k, _ in go.named_parameters()]
+    tail_params = [k for k in names if k.startswith("1.")] + names[-4:-2]          # the 1x1 conv and the generator's last Conv2d (weight, bias)
+    for fuse in ("1", "0"):
+        y, grads = res[fuse]
+        assert tuple(y.shape) == tuple(yo.shape) and float((y.detach() - yo.detach()).norm() / yo.detach().norm()) <= 3e-2, fuse
+        for k in tail_params:       # next to the output: comparable with the fp32 oracle (deeper gradients carry bf16 ReLU-mask flips, DESIGN 4)
+            ref = dict(go.named_parameters())[k].grad
+            assert float((grads[k] - ref).norm() / ref.norm()) <= 6e-2, (fuse, k)
+    assert float((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()) <= 2e-2
+    for k in names:                 # fused vs layer by layer: the activations in front of the tail — hence every ReLU mask — are identical
+        a, b = res["1"][1][k], res["0"][1][k]
+        if k.endswith("weight") or k in tail_params:   # (the bias of a conv in front of an InstanceNorm has a zero gradient: rounding noise only)
+            # (a bias gradient is w_b[m] * sum_v g(v): a sum with cancellation, whose bf16 rounding noise is the same factor for every channel)
+            assert float((a - b).norm() / b.norm()) <= (3e-2 if k.endswith("weight") else 8e-2), k
+
+
 @pytest.mark.parametrize("const_up,padding,down", [(True, "valid", "convolve"), (False, "valid", "convolve"),
                                                    (True, "same", "convolve"), (True, "valid", "max"), (False, "valid", "max")])
 def test_unet_2d_vs_oracle(const_up, padding, down):
