@@ -15,6 +15,18 @@ class BaseCompetentLoss(torch.nn.Module):
         if hasattr(self, "gan_mode"):
             self.gan_loss = GANLoss(gan_mode=self.gan_mode)
         self.loss_dict = {}
+        self.scaler = None   # amp.LossScaler (f16-storage training, config "precision": "f16"): set by the train driver; None = plain bf16 step
+
+    def _backward(self, loss, **kw):
+        """loss.backward(**kw) — through the loss scaler when one is set (no reference counterpart: the reference trains in fp32)."""
+        (self.scaler.scale(loss) if self.scaler is not None else loss).backward(**kw)
+
+    def _step(self, optimizer):
+        """optimizer.step(), or the scaler's checked step (skipped, scale halved, when a gradient overflowed)."""
+        if self.scaler is not None:
+            self.scaler.step(optimizer)
+        else:
+            optimizer.step()
 
     def set_requires_grad(self, nets, requires_grad=False):
         """BaseCompetentLoss.py:20-31."""

@@ -49,7 +49,7 @@ class LinkCycleLoss(BaseCompetentLoss):
                 this_loss = self.gan_loss(dnet(data_dict[key].detach()), key == "real")
                 self.loss_dict.update({f"Discriminator_{side}/{key}": this_loss})
                 loss += lambda_ * this_loss
-        loss.backward()
+        self._backward(loss)
         return loss
 
     def backward_Ds(self, data_dict, n_loop=5):
@@ -61,14 +61,14 @@ class LinkCycleLoss(BaseCompetentLoss):
                 loss_D1 = self.backward_D("B", self.netD1, data_dict["B"])
                 loss_D2 = self.backward_D("A", self.netD2, data_dict["A"])
                 self._sync(self.optimizer_D)
-                self.optimizer_D.step()
+                self._step(self.optimizer_D)
                 self.clamp_weights(self.netD1)
                 self.clamp_weights(self.netD2)
         else:
             loss_D1 = self.backward_D("B", self.netD1, data_dict["B"])
             loss_D2 = self.backward_D("A", self.netD2, data_dict["A"])
             self._sync(self.optimizer_D)
-            self.optimizer_D.step()
+            self._step(self.optimizer_D)
         self.set_requires_grad([self.netG1, self.netG2], True)
         return loss_D1, loss_D2
 
@@ -96,7 +96,7 @@ class LinkCycleLoss(BaseCompetentLoss):
                         this_loss = getattr(self, fcn_name)(real, pred)
                     self.loss_dict.update({f"{fcn_name}/{key}_{side}": this_loss})
                     loss += lambda_ * this_loss
-        loss.backward(retain_graph=self._retain_graph())
+        self._backward(loss, retain_graph=self._retain_graph())
         return loss
 
     def backward_Gs(self, data_dict):
@@ -106,7 +106,7 @@ class LinkCycleLoss(BaseCompetentLoss):
         loss_G1 = self.backward_G("B", self.netG1, self.netD1, data_dict["B"])
         loss_G2 = self.backward_G("A", self.netG2, self.netD2, data_dict["A"])
         self._sync(self.optimizer_G)
-        self.optimizer_G.step()
+        self._step(self.optimizer_G)
         self.set_requires_grad([self.netD1, self.netD2], True)
         return loss_G1, loss_G2
 

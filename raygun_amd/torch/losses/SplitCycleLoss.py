@@ -30,12 +30,12 @@ class SplitCycleLoss(LinkCycleLoss):
         self.optimizer_G1.zero_grad(set_to_none=True)
         loss_G1 = self.backward_G("B", self.netG1, self.netD1, data_dict["B"])
         self._sync(self.optimizer_G1)
-        self.optimizer_G1.step()
+        self._step(self.optimizer_G1)
         self.set_requires_grad([self.netG2], True)
         self.set_requires_grad([self.netG1], False)
         self.optimizer_G2.zero_grad(set_to_none=True)
         loss_G2 = self.backward_G("A", self.netG2, self.netD2, data_dict["A"])
         self._sync(self.optimizer_G2)
-        self.optimizer_G2.step()
+        self._step(self.optimizer_G2)
         self.set_requires_grad([self.netG1, self.netD1, self.netD2], True)
         return loss_G1, loss_G2

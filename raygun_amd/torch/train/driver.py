@@ -28,12 +28,16 @@ def _names(fn):
 
 def train_step(model, loss_fn, optimizer, batch, grad_sync=None, scaler=None):
     """One iteration.  Returns (loss, outputs dict).  `scaler` (amp.LossScaler): f16 storage with dynamic loss scaling — the
-    config's "precision": "f16" — for systems whose loss leaves backward and step to the driver (MTLSD)."""
+    config's "precision": "f16".  MTLSD leaves backward and step to this driver; the CycleGAN losses own both and take the scaler as
+    `loss_fn.scaler` (every backward of theirs is scaled, every optimiser step checked)."""
     if hasattr(optimizer, "zero_grad"):
         optimizer.zero_grad()
-    if scaler is not None and not isinstance(optimizer, torch.optim.Optimizer):
-        raise RuntimeError("raygun_amd.train_step: loss scaling needs a loss that leaves backward() and step() to the driver "
-                           "(the CycleGAN losses own both: train them in bf16)")
+    own_step = not isinstance(optimizer, torch.optim.Optimizer)   # the CycleGAN losses own backward + step (LinkCycleLoss.py:87-135)
+    if scaler is not None and own_step:
+        if not hasattr(loss_fn, "_backward"):
+            raise RuntimeError("raygun_amd.train_step: loss scaling with a loss that owns backward() and step() needs raygun_amd's "
+                               "BaseCompetentLoss (its _backward / _step go through the scaler)")
+        loss_fn.scaler = scaler
     in_names = _names(model.forward)
     with (ops.precision("f16") if scaler is not None else contextlib.nullcontext()):
         outs = model(**{k: batch[k] for k in in_names if k in batch})
@@ -41,10 +45,10 @@ def train_step(model, loss_fn, optimizer, batch, grad_sync=None, scaler=None):
         named = dict(zip(model.output_arrays, outs))
         pool = {**batch, **named}
         loss = loss_fn(*[pool[k] for k in _names(loss_fn.forward)])
-    (scaler.scale(loss) if scaler is not None else loss).backward()  # a no-op for the CycleGAN losses, which own their backward+step (LinkCycleLoss.py:173)
+    (scaler.scale(loss) if scaler is not None and not own_step else loss).backward()  # a no-op for the CycleGAN losses, which own their backward+step (LinkCycleLoss.py:173)
     if grad_sync is not None and isinstance(optimizer, torch.optim.Optimizer):
         grad_sync([p for g in optimizer.param_groups for p in g["params"]])
-    if scaler is not None:
+    if scaler is not None and not own_step:
         scaler.step(optimizer)
     else:
         optimizer.step()

@@ -123,3 +123,49 @@ def test_mtlsd_196_f16_train_step_with_loss_scaling_vs_reference():
     assert sc.step(opt) is True and sc.skipped == 0
     moved = (P["aff_head.conv_pass.0.weight"].detach() - w0).abs().max()
     assert 0 < float(moved) <= 1.01 * 0.5e-4       # Adam's first step: lr * g / (|g| + eps)
+
+
+def test_cyclegan_link_and_split_steps_in_f16_with_loss_scaling():
+    """The CycleGAN losses own their backward + step calls (LinkCycleLoss.py:87-135, SplitCycleLoss.py:116-151): with `loss.scaler` set by the train
+    driver every backward is scaled and every optimiser step goes through the scaler's overflow check.  Three iterations of a small 3-D CycleGAN in
+    f16 storage against the same iterations in bf16: finite losses that agree with the bf16 run's within the bf16 policy, all optimisers stepped
+    (Adam's step counts), no step skipped at the initial scale."""
+    import functools
+    from raygun_amd import amp
+    from raygun_amd.torch.systems import CycleGAN
+    from raygun_amd.torch.train.driver import train_step
+    dev = torch.device("cuda")
+    IN = functools.partial(torch.nn.InstanceNorm3d)
+    A = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 42)).to(dev)
+    B = torch.from_numpy(synth.uniform((1, 1, 32, 32, 32), 1042)).to(dev)
+    for loss_type in ("link", "split"):
+        runs = {}
+        for prec in ("bf16", "f16"):
+            cfg = dict(common_voxel_size=[1, 1, 1], ndims=3, gnet_type="resnet",
+                       gnet_kwargs=dict(input_nc=1, ngf=8, n_blocks=2, n_downsampling=2, norm_layer=IN, padding_type="same"),
+                       dnet_kwargs=dict(input_nc=1, ngf=8, n_layers=3, kw=4), loss_type=loss_type, loss_kwargs={},
+                       g_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), d_optim_kwargs=dict(betas=[0.5, 0.999], lr=5e-4), random_seed=None)
+            s = CycleGAN(cfg)
+            s.setup_networks()
+            for i, k in enumerate(["netG1", "netG2", "netD1", "netD2"]):
+                net = getattr(s, k)
+                net.load_state_dict(synth.fill_state_dict(net.state_dict(), 80 + i)); net.to(dev)
+            s.setup_model(); s.setup_optimization()
+            sc = amp.LossScaler(init_scale=2.0 ** 12) if prec == "f16" else None
+            recs = []
+            for it in range(3):
+                loss, outs = train_step(s.model, s.loss, s.optimizer, {"real_A": A, "real_B": B}, None, sc)
+                recs.append({k: float(v) for k, v in s.loss.loss_dict.items()})
+            runs[prec] = recs
+            if sc is not None:
+                assert s.loss.scaler is sc and sc.skipped == 0 and sc.clean_steps == 3 * (2 if loss_type == "link" else 3)
+                opts = [v for v in vars(s.optimizer).values() if isinstance(v, torch.optim.Optimizer)]
+                assert len(opts) == (2 if loss_type == "link" else 3)
+                assert all(float(next(iter(o.state.values()))["step"]) == 3.0 for o in opts)
+        for it in range(3):
+            for k, v in runs["bf16"][it].items():
+                w = runs["f16"][it][k]
+                # iteration 0 is a pure forward difference of the two storage types; later ones also carry one / two Adam updates at lr 5e-4 whose
+                # sign-like first steps amplify rounding differences (the fixture tests give the bf16 run 6 % against the fp32 reference there)
+                # (the lsgan terms of these tiny nets move by tens of percent per update: after two updates only the order of magnitude is comparable)
+                assert np.isfinite(w) and abs(w - v) <= (0.03 if it == 0 else 0.15 if it == 1 else 0.5) * max(abs(v), 0.05), (loss_type, it, k, v, w)
