@@ -118,6 +118,13 @@ int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias,
  * backward-data pass of the 432 <- 2592 layer at 21^3, the PatchGAN's 15^3 layers) split K over up to 8 workgroups per tile, fp32
  * partial sums go through the workspace and a second pass applies bias + activation.  rg_conv3d_igemm_workspace_bytes returns an
  * upper bound (0: never splits); a NULL / too small workspace simply runs unsplit. */
+/* A stride-2 / pad-1 / 3^3 ConvTranspose3d (networks/ResNet.py:325-333; equally the backward-data pass of the stride-2 Conv3d of :291-298) as ONE
+ * convolution on the input grid — 8 parity classes x C channels = 8 C columns, 2^3 taps (weights: the sub-pixel rearrangement, packed like any
+ * forward operand) — whose epilogue writes column block q = (qd, qh, qw) of row r to channel c of output voxel 2 r + q: no intermediate tensor,
+ * no shuffle pass.  y: (N, C, 2 R0, 2 R1, 2 R2), C % 16 == 0; bias: C floats or NULL; p->cout = 8 C, p->T = (2, 2, 2).  dry_run != 0 only
+ * answers whether the problem can run this way (RG_OK) — otherwise use rg_conv3d_igemm2 + rg_d2s_add_act. */
+int rg_conv3d_igemm_d2s(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y, const rg_conv_params* p,
+                        int32_t dry_run, rg_stream s);
 int64_t rg_conv3d_igemm_workspace_bytes(const rg_tensor* x, const rg_tensor* y, const rg_conv_params* p);
 int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                      const rg_conv_params* p, void* workspace, size_t ws_bytes, rg_stream s);

@@ -56,6 +56,7 @@ _SIGS = {
     "rg_pack_weights_bytes": (C.c_int64, [_P(rg_pack_params)]),
     "rg_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
     "rg_conv3d_igemm": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p]),
+    "rg_conv3d_igemm_d2s": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_int32, C.c_void_p]),
     "rg_conv3d_igemm_workspace_bytes": (C.c_int64, [_T, _T, _P(rg_conv_params)]),
     "rg_conv3d_igemm2": (C.c_int, [_T, C.c_void_p, C.c_void_p, _T, _P(rg_conv_params), C.c_void_p, C.c_size_t, C.c_void_p]),
     "rg_wino_weights_rows": (C.c_int64, [C.c_int32]),

@@ -29,6 +29,26 @@ static const void* zero_page() {
   return cache[dev];
 }
 
+int rg_launch_igemm5_d2s(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int dry);   // conv4.hip
+// Stride-2 / pad-1 / 3^3 transposed convolution (ResNet.py:325-333's up path; the backward-data pass of the stride-2 convolutions :291-298) in its
+// sub-pixel form with the depth-to-space shuffle in the GEMM's epilogue: p describes the (8 * C)-column, 2^3-tap convolution on the INPUT grid
+// (R = input spatial size, cout = 8 * C, weights packed from ops._subpixel_weights_t), y is the (N, C, 2D, 2H, 2W) output, bias has C entries.
+// Column block q = (qd, qh, qw) of row r lands on output voxel 2 r + q.  dry_run != 0: RG_OK if this problem can run this way, nothing is launched.
+extern "C" int rg_conv3d_igemm_d2s(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y, const rg_conv_params* p,
+                                   int32_t dry_run, rg_stream s) {
+  CL5 X, Y;
+  int rc;
+  if ((rc = rg_as_cl5(x, &X, "conv_d2s.x")) || (rc = rg_as_cl5(y, &Y, "conv_d2s.y"))) return rc;
+  if (!p || (!dry_run && (!w_packed || (((uintptr_t)w_packed) & 15)))) RG_FAIL(RG_ERR_BAD_SHAPE, "conv_d2s: null / misaligned weights or params");
+  if (p->cout != 8 * Y.C || Y.C % 16 || Y.lanes != Y.C || X.N != Y.N) RG_FAIL(RG_ERR_UNSUPPORTED, "conv_d2s: needs cout == 8 * C with C a multiple of 16 (C = %d, cout = %d)", Y.C, p->cout);
+  if (Y.D != 2 * p->R[0] || Y.H != 2 * p->R[1] || Y.W != 2 * p->R[2]) RG_FAIL(RG_ERR_BAD_SHAPE, "conv_d2s: y must be twice the row grid along every axis");
+  if (rg_conv3d_kalign(X.C, p->cout) != 64) RG_FAIL(RG_ERR_UNSUPPORTED, "conv_d2s: the 64-lane K packing only");
+  for (int d = 0; d < 3; ++d) if (p->R[d] <= 0 || p->T[d] <= 0 || p->rstride[d] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "conv_d2s: unit row stride, non-empty grid");
+  if ((rc = rg_launch_igemm5_d2s(X, Y, w_packed, bias, p, (hipStream_t)s, dry_run))) return rc;
+  if (!dry_run) RG_CHECK_LAUNCH();
+  return RG_OK;
+}
+
 extern "C" int rg_conv3d_igemm(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                                const rg_conv_params* p, rg_stream s) {
   return rg_conv3d_igemm2(x, w_packed, bias, y, p, nullptr, 0, s);

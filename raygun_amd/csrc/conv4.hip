@@ -432,14 +432,20 @@ bool rg_igemm5_ok(const Igemm4Args& a, bool flat, size_t ws_bytes);
 int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_t ws_bytes);
 struct Igemm4Batch { int n; long xs, ws, ys; };
 static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
-                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt);
+                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt, int d2s_c = 0);
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                      void* workspace, size_t ws_bytes) {
   return launch_igemm4_any(X, Y, w_packed, bias, p, st, flat, workspace, ws_bytes, nullptr);
 }
+// the sub-pixel form of a stride-2 transposed convolution with the depth-to-space shuffle in igemm5's epilogue (conv.hip: rg_conv3d_igemm_d2s);
+// dry != 0: only answer whether this problem can run that way (RG_OK / RG_ERR_UNSUPPORTED)
+int rg_launch_igemm5_d2s(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int dry) {
+  return launch_igemm4_any(X, Y, w_packed, bias, p, st, 0, nullptr, 0, nullptr, dry ? -Y.C : Y.C);
+}
 static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
-                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt) {
+                             void* workspace, size_t ws_bytes, const Igemm4Batch* bt, int d2s_c) {
   Igemm4Args a;
+  a.d2s_c = 0;
   a.nbatch = bt ? bt->n : 1; a.xbatch = bt ? bt->xs : 0; a.wbatch = bt ? bt->ws : 0; a.ybatch = bt ? bt->ys : 0;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;
@@ -471,6 +477,14 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
+  if (d2s_c) {   // columns = 8 parity classes x |d2s_c| channels, written interleaved (no split-K: the combine kernel does not shuffle)
+    a.cout_lanes = round_up(p->cout, 8);
+    a.os[0] = a.os[1] = a.os[2] = 2; a.oo[0] = a.oo[1] = a.oo[2] = 0;
+    if (!rg_igemm5_ok(a, false, 0)) { rg_set_error("conv_d2s: no igemm5 tiling without split-K for this problem"); return RG_ERR_UNSUPPORTED; }
+    if (d2s_c < 0) return RG_OK;
+    a.d2s_c = d2s_c;
+    return rg_launch_igemm5(a, check, st, nullptr, 0);
+  }
   if (rg_igemm5_ok(a, flat != 0, ws_bytes)) return rg_launch_igemm5(a, check, st, (float*)workspace, ws_bytes);   // 256 x 288 / 256 tiles, both operands through LDS by LDS-DMA (gemm5.hip)
   if (flat && rg_halo16_ok(X, Y, p) && !rg_opt(RG_OPT_NO_HALO)) return rg_launch_halo16(X, Y, w_packed, bias, p, a.krow, st);
   if (flat && rg_igemm_thin_ok(X, p) && a.M < (1L << 31) && cl5_extent(Y) < (1L << 31) && !rg_opt(RG_OPT_NO_THIN)) return rg_launch_igemm_thin(a, check, st);

@@ -239,17 +239,22 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
     for (int j = 0; j < FN; ++j) {
       const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
       if (c >= a.cout_lanes) continue;
+      int cc = c; long yo = 0;
+      if (a.d2s_c) {   // depth-to-space: column block q = c / C is parity (qd, qh, qw) of output voxel 2 * row + parity (the 4 columns share q: C % 16 == 0)
+        const int q = c / a.d2s_c; cc = c - q * a.d2s_c;
+        yo = (long)((q >> 2) & 1) * a.ysd + (long)((q >> 1) & 1) * a.ysh + (long)(q & 1) * a.ysw;
+      }
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = 0.f;
         if (c + r < a.cout) {
-          v = acc[i][j][r] + (a.bias ? a.bias[c + r] : 0.f);
+          v = acc[i][j][r] + (a.bias ? a.bias[cc + r] : 0.f);
           v = act_fwd(v, a.act, a.slope);
         }
         o[r] = (short)f2bf(v);
       }
-      *(bf16x4*)(yrow + c) = o;
+      *(bf16x4*)(yrow + yo + cc) = o;
     }
   }
 }
@@ -304,7 +309,8 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
     hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
     hipFuncSetAttribute((const void*)igemm5_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
   });
-  rg_set_kernel_name("igemm5_kernel<%d,%d>%s", (int)check, pl.fn, pl.ksplit > 1 ? "+splitK" : "");
+  if (a.d2s_c && pl.ksplit > 1) { rg_set_error("igemm5: depth-to-space epilogue with split-K"); return RG_ERR_UNSUPPORTED; }
+  rg_set_kernel_name("igemm5_kernel<%d,%d>%s", (int)check, pl.fn, pl.ksplit > 1 ? "+splitK" : (a.d2s_c ? "+d2s" : ""));
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * a.nbatch));
   if (pl.fn == 9) {
     if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);

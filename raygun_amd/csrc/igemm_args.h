@@ -18,5 +18,7 @@ struct Igemm4Args {
   int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
   int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
   int nbatch; long xbatch, wbatch, ybatch;  // batched GEMM (rg_gemm_batched): element strides between the problems; no split-K
+  int d2s_c;  // igemm5 only, 0 = off: the columns are 8 parity classes x d2s_c channels of a sub-pixel (stride-2 transposed) convolution — column
+              // c goes to channel c % d2s_c of output voxel 2 * row + parity(c / d2s_c) (depth-to-space in the epilogue; os = 2, bias per channel)
 };
 

@@ -657,9 +657,25 @@ def _subpixel_weights_t(w):
 def _scatter_conv(src, w, bias, out, stride, pad, K, swap, act, slope):
     """out[o] = act(bias + sum_{i,k: o = i*s - p + k} src[i] . W[..k])  as one igemm launch per parity class."""
     size = out.shape[2:]
-    if (swap and tuple(stride) == (2, 2, 2) and tuple(K) == (3, 3, 3) and tuple(pad) == (1, 1, 1) and out.shape[1] % 8 == 0
-            and src.shape[1] >= 192 and all(o == 2 * i for o, i in zip(size, src.shape[2:]))
-            and os.environ.get("RAYGUN_AMD_SUBPIXEL_T", "1") != "0"):
+    subpix = (swap and tuple(stride) == (2, 2, 2) and tuple(K) == (3, 3, 3) and tuple(pad) == (1, 1, 1) and out.shape[1] % 8 == 0
+              and all(o == 2 * i for o, i in zip(size, src.shape[2:])) and os.environ.get("RAYGUN_AMD_SUBPIXEL_T", "1") != "0")
+    if subpix and src.shape[1] >= 128 and out.shape[1] % 16 == 0 and out.stride(4) == out.shape[1] and os.environ.get("RAYGUN_AMD_D2S_EPILOGUE", "1") != "0":
+        # the 8 parity classes as ONE convolution with 8*Cout columns and 2^3 taps on the input grid, its epilogue writing every column block
+        # to its own output parity (rg_conv3d_igemm_d2s, igemm5): no 8*Cout-channel intermediate, no shuffle pass — 128 -> 64 at 64^3 used to be
+        # eight parity launches re-reading the input (0.45 ms per call), 256 -> 128 at 32^3 a sub-pixel convolution + depth-to-space
+        n, _, D, H, W = src.shape
+        p = _conv_params(R=(D, H, W), T=(2, 2, 2), rstride=(1, 1, 1), tbase=(0, 0, 0), tstep=(1, 1, 1), ostride=(2, 2, 2),
+                         ooffset=(0, 0, 0), cout=8 * out.shape[1], act=act, slope=slope)
+        dsrc, dout = desc(src), desc(out)
+        if _L().rg_conv3d_igemm_d2s(C.byref(dsrc), None, None, C.byref(dout), C.byref(p), 1, _stream()) == 0:
+            wp = pack_weights(_subpixel_weights_t(w), swap=0)
+            b = bias.detach().float().contiguous() if bias is not None else None
+            _timed(_conv_flops(p, src.shape[0], src.shape[1], 8 * out.shape[1]),
+                   lambda: _lib.check(_L().rg_conv3d_igemm_d2s(C.byref(dsrc), C.c_void_p(wp.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None,
+                                                               C.byref(dout), C.byref(p), 0, _stream()), "rg_conv3d_igemm_d2s"),
+                   lambda: f"x{tuple(src.shape)} -> y{tuple(out.shape)} R{tuple(p.R)} T{tuple(p.T)} sub-pixel + d2s epilogue")
+            return
+    if subpix and src.shape[1] >= 192:
         # wide inputs: the 8 parity classes as ONE convolution with 8*Cout channels and 2^3 taps on the input grid (64/27 of
         # the FLOPs, in one launch that fills the chip instead of eight 16-tile launches with 1..8-tap K loops: 256 -> 128 at
         # 32^3 takes 0.18 ms instead of 0.64), then a depth-to-space shuffle

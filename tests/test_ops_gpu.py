@@ -525,6 +525,50 @@ def test_wide_transposed_conv_subpixel_path():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,act", [(128, 64, (30, 32, 24), "relu"), (256, 128, (24, 24, 20), "none"), (128, 32, (36, 40, 32), "leaky"),
+                                             (128, 64, (6, 5, 4), "none")])   # (>= 180 tiles of 256 x 256 for the first three: igemm5 without a K split)
+def test_transposed_conv_subpixel_with_depth_to_space_epilogue(cin, cout, sp, act, monkeypatch):
+    """rg_conv3d_igemm_d2s: the stride-2 / k3 / pad-1 transposed convolution as ONE 8*Cout-column convolution whose epilogue writes every column
+    block to its output parity (no intermediate, no shuffle pass) — ConvTranspose3d forward (+ bias, + activation) and the input gradient of the
+    stride-2 Conv3d, against torch fp32 on the CPU and bit for bit against the two-pass form (RAYGUN_AMD_D2S_EPILOGUE=0) where that one exists;
+    problems whose grid igemm5 would have to K-split (the last case) fall back by themselves."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    x0 = bf(torch.randn(1, cin, *sp)); w0 = bf(torch.randn(cin, cout, 3, 3, 3) * (1.0 / (cin * 27) ** 0.5)); b0 = torch.randn(cout) * 0.1
+    afn = {"none": lambda t: t, "relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+    ref = afn(F.conv_transpose3d(x, w, b0, stride=2, padding=1, output_padding=1))
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RAYGUN_AMD_D2S_EPILOGUE", flag)
+        xd, wd = x0.clone().to(dev).requires_grad_(), w0.clone().to(dev).requires_grad_()
+        ops.profile_start()
+        got = ops.conv_transpose3d(xd, wd, b0.to(dev), stride=2, padding=1, output_padding=1, act=act, slope=0.2)
+        names = list(ops.profile_stop())
+        assert tuple(got.shape) == tuple(ref.shape)
+        assert (got.float().cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item()), flag
+        go = bf(torch.randn(ref.shape))
+        for a, r in zip(torch.autograd.grad(got, (xd, wd), go.to(dev).to(got.dtype)), torch.autograd.grad(ref, (x, w), go, retain_graph=True)):
+            assert (a.float().cpu() - r).abs().max().item() <= 2e-2 * r.abs().max().item() + 1e-6
+        outs[flag] = (got.detach().float().cpu(), names)
+    fused = any("+d2s" in n for n in outs["1"][1])
+    assert fused == (sp != (6, 5, 4)), outs["1"][1]              # big enough grids take the fused epilogue
+    assert not any("+d2s" in n for n in outs["0"][1])
+    if fused and cin >= 192:                                     # same GEMM, same rounding: the shuffle pass only moves data
+        assert torch.equal(outs["1"][0], outs["0"][0])
+    # the backward-data pass of the stride-2 convolution is the same scatter
+    xs0 = bf(torch.randn(1, cout, *[2 * v for v in sp])); ws = bf(torch.randn(cin, cout, 3, 3, 3) * 0.05); gs = bf(torch.randn(1, cin, *sp))
+    xs = xs0.clone().requires_grad_()
+    (rg,) = torch.autograd.grad(F.conv3d(xs, ws, None, stride=2, padding=1), xs, gs)
+    monkeypatch.setenv("RAYGUN_AMD_D2S_EPILOGUE", "1")
+    xsd = xs0.clone().to(dev).requires_grad_()
+    yd = ops.conv3d(xsd, ws.to(dev), None, stride=2, padding=1)
+    (gg,) = torch.autograd.grad(yd, xsd, gs.to(dev).to(yd.dtype))
+    assert (gg.float().cpu() - rg).abs().max().item() <= 2e-2 * rg.abs().max().item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cout", [144, 128])
 def test_igemm4_192_row_tiles(cout):
     """The 192-row tile (FM = 3) of igemm4 is only picked for large grids; force it (RG_FM=3) on a small problem: forward and
