@@ -454,6 +454,50 @@ def test_conv3d_linear_pair_equals_two_layers(cin, mid, P, k, pad, sp, act):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,kw,sp,pad,act", [(49, 64, 7, (34, 36, 70), 0, "relu"), (64, 49, 7, (33, 34, 134), 0, "none"),
+                                                    (49, 64, 7, (32, 33, 128), 3, "none"), (64, 64, 5, (40, 30, 50), 2, "leaky")])
+def test_line_convolution_kernel(cin, cout, kw, sp, pad, act):
+    """conv6.hip `linew_kernel` — the folded 7^3 stem / composed tail shapes: a (kw,1,1) convolution run D<->W exchanged (taps along the innermost
+    axis), 49 or 64 channels in, <= 64 out, >= 1024 lines — forward (bias, activation, zero padding along the tap axis) and the input gradient
+    (the tap-reversed direction) against torch fp32 on the CPU, and against the default kernels on the same operands.  Opt-in (RG_LINEW): a measured
+    step-level tie (conv6.hip header)."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(11)
+    d, h, w = sp                                         # the op below convolves along D: conv_kd_as_kw swaps D and W
+    x0 = bf(torch.randn(1, cin, w, h, d)); w0 = bf(torch.randn(cout, cin, kw, 1, 1) * (1.0 / (cin * kw) ** 0.5)); b0 = torch.randn(cout) * 0.1
+    afn = {"none": lambda t: t, "relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    x = x0.clone().requires_grad_()
+    ref = afn(F.conv3d(x, w0, b0, 1, (pad, 0, 0)))
+    go = bf(torch.randn(ref.shape))
+    (gref,) = torch.autograd.grad(ref, x, go)
+    res = {}
+    for off in (0, 1):
+        with ops.option("RG_LINEW", 1 - off):
+            xd = x0.clone().to(dev).requires_grad_()
+            # the folded stem / tail tensors live D<->W exchanged in memory (ops.cl_empty_dw): the tap axis is the innermost spatial axis
+            xcl = ops.enter(xd.transpose(2, 4).contiguous())
+            xin = (ops.pad3d(xcl, (0, 0, pad), "zeros") if pad else xcl).transpose(2, 4)
+            ops.profile_start()
+            ycl = ops.conv_kd_as_kw(xin, w0.to(dev), b0.to(dev), act, 0.2)
+            names = list(ops.profile_stop())
+            y = ops.leave(ycl)
+            gdw = ops.enter(go.to(dev).transpose(2, 4).contiguous()).transpose(2, 4)     # the incoming gradient in the same exchanged layout
+            ops.profile_start()
+            (gx,) = torch.autograd.grad(ycl, xd, gdw)
+            names += list(ops.profile_stop())
+        assert tuple(y.shape) == tuple(ref.shape)
+        assert (y.detach().cpu() - ref.detach()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item()), off
+        assert (gx.cpu() - gref).abs().max().item() <= 2e-2 * gref.abs().max().item(), off
+        res[off] = (y.detach().cpu(), gx.cpu(), names)
+    want = 2 if cin == 64 else 1          # (56-lane inputs: the forward direction stays on igemm4's FLAT path, measured faster there)
+    assert sum("linew" in n for n in res[0][2]) == want and not any("linew" in n for n in res[1][2]), (res[0][2], res[1][2])
+    # same operands, fp32 accumulation in a different order: the two kernels agree far inside the bf16 policy
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 4e-3 * max(1.0, res[1][0].abs().max().item())
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 4e-3 * max(1.0, res[1][1].abs().max().item())
+
+
+@pytest.mark.gpu
 def test_diag_spread_sum_are_exact_adjoint_gathers():
     """rg_diag_spread / rg_diag_sum (in-plane taps <-> channels) are pure data movement + an fp32 sum: exact against numpy
     indexing on bf16-exact data, both signs."""
