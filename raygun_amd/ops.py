@@ -809,6 +809,13 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, act="none", slope=0.0):
         if any(padding):
             x = pad3d(x, padding, "zeros")
         kd, kh, kw = weight.shape[2:]
+        if os.environ.get("RAYGUN_AMD_FOLD_DH", "1") != "0":
+            # fold (kd, kh) instead: the remaining KW taps run along the memory-fastest axis of an ORDINARY channels-last tensor (no D<->W exchanged
+            # views: those put the tap axis a 2-MB plane apart per row); the spread map works on the transposed view and writes the exchanged layout
+            xT = x.transpose(2, 4)
+            sT = _DiagSpread.apply(xT, kh, kd, 1, xT.shape[3] - kh + 1, xT.shape[4] - kd + 1, True)     # channel kh * KD + kd
+            wf = weight.permute(0, 3, 2, 4, 1).reshape(weight.shape[0], kh * kd, 1, 1, kw)
+            return _Conv3d.apply(sT.transpose(2, 4), wf, bias, (1, 1, 1), (0, 0, 0), act, float(slope))
         xf = _DiagSpread.apply(x, kh, kw, 1, x.shape[3] - kh + 1, x.shape[4] - kw + 1)
         wf = weight.permute(0, 3, 4, 2, 1).reshape(weight.shape[0], kh * kw, kd, 1, 1)  # [cout][(kh,kw)][kd]
         return conv_kd_as_kw(xf, wf, bias, act, slope)
@@ -844,10 +851,18 @@ def conv3d_linear_pair(x, w_a, b_a, w_b, b_b, padding=0, act="none", slope=0.0):
             bc = bc + b_b.float()
     if P == 1 and KH * KW <= 64 and os.environ.get("RAYGUN_AMD_FOLD_HW", "1") != "0":
         # (kh,kw) -> output channels: a KD-tap conv to KH*KW channels over the padded plane, then the diagonal gather
-        w1 = wc.permute(0, 3, 4, 1, 2).reshape(KH * KW, wc.shape[1], KD, 1, 1)           # channel kh*KW+kw
         x = enter(x)
         if any(padding):
             x = pad3d(x, padding, "zeros")                                                # H, W extents grow by 2*pad
+        if os.environ.get("RAYGUN_AMD_FOLD_DH", "1") != "0" and KD * KH <= 64:
+            # (kd, kh) -> output channels instead: the KW taps run along the memory-fastest axis of the ordinary channels-last input (conv3d's fold
+            # branch has the reason); the diagonal gather then works on the D<->W transposed view and hands back the exchanged layout
+            w1 = wc.permute(0, 3, 2, 1, 4).reshape(KH * KD, wc.shape[1], 1, 1, KW)       # channel kh*KD+kd, taps along W
+            z = _Conv3d.apply(x, w1, None, (1, 1, 1), (0, 0, 0), "none", 0.0)
+            zT = z.transpose(2, 4)
+            yT = _DiagSum.apply(zT, KH, KD, 1, zT.shape[3] - KH + 1, zT.shape[4] - KD + 1, bc, True)
+            return activation(yT.transpose(2, 4), act, slope)
+        w1 = wc.permute(0, 3, 4, 1, 2).reshape(KH * KW, wc.shape[1], KD, 1, 1)           # channel kh*KW+kw
         z = conv_kd_as_kw(x, w1, None)
         y = _DiagSum.apply(z, KH, KW, 1, z.shape[3] - KH + 1, z.shape[4] - KW + 1, bc)
         return activation(y, act, slope)
@@ -1337,43 +1352,43 @@ class _DiagSpread(Function):
     """y[.,h,w][kh*KW+kw] = x[.,h+s*kh,w+s*kw][0] on an (oh, ow) output grid; adjoint: _DiagSum with -s."""
 
     @staticmethod
-    def forward(ctx, x, kh, kw, sign, oh, ow):
+    def forward(ctx, x, kh, kw, sign, oh, ow, dw=False):
         _require_cuda(x, "diag_spread")
         x = as_cl(x)
         n, _, d, h, w = x.shape
-        y = cl_empty(n, kh * kw, d, oh, ow, x.device)
+        y = (cl_empty_dw if dw else cl_empty)(n, kh * kw, d, oh, ow, x.device)   # dw: memory with D and W exchanged (the caller transposes back)
         _lib.check(_L().rg_diag_spread(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign, _stream()), "rg_diag_spread")
-        ctx.cfg = (kh, kw, sign, h, w)
+        ctx.cfg = (kh, kw, sign, h, w, d > 1 and w > 1 and x.stride(2) < x.stride(4))   # (input was itself a D<->W exchanged view: so is its gradient)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        kh, kw, sign, h, w = ctx.cfg
-        return _DiagSum.apply(g, kh, kw, -sign, h, w, None), None, None, None, None, None
+        kh, kw, sign, h, w, in_dw = ctx.cfg
+        return _DiagSum.apply(g, kh, kw, -sign, h, w, None, in_dw), None, None, None, None, None, None
 
 
 class _DiagSum(Function):
     """y[.,h,w][0] = bias + sum_{kh,kw} x[.,h+s*kh,w+s*kw][kh*KW+kw] on an (oh, ow) grid; adjoint: _DiagSpread with -s."""
 
     @staticmethod
-    def forward(ctx, x, kh, kw, sign, oh, ow, bias):
+    def forward(ctx, x, kh, kw, sign, oh, ow, bias, dw=False):
         _require_cuda(x, "diag_sum")
         x = as_cl(x)
         n, _, d, h, w = x.shape
-        y = cl_empty(n, 1, d, oh, ow, x.device)
+        y = (cl_empty_dw if dw else cl_empty)(n, 1, d, oh, ow, x.device)
         b = bias.detach().float().contiguous() if bias is not None else None
         _lib.check(_L().rg_diag_sum(C.byref(desc(x)), C.byref(desc(y)), kh, kw, sign,
                                           C.c_void_p(b.data_ptr()) if b is not None else None, _stream()), "rg_diag_sum")
-        ctx.cfg = (kh, kw, sign, h, w, bias is not None)
+        ctx.cfg = (kh, kw, sign, h, w, bias is not None, d > 1 and w > 1 and x.stride(2) < x.stride(4))
         return y
 
     @staticmethod
     def backward(ctx, g):
-        kh, kw, sign, h, w, has_bias = ctx.cfg
+        kh, kw, sign, h, w, has_bias, in_dw = ctx.cfg
         gb = None
         if has_bias and ctx.needs_input_grad[6]:
             gb = _act_bwd_bias(as_cl(g), None, "none", 0.0, True)[1].reshape(1)
-        return _DiagSpread.apply(g, kh, kw, -sign, h, w), None, None, None, None, None, gb
+        return _DiagSpread.apply(g, kh, kw, -sign, h, w, in_dw), None, None, None, None, None, gb, None
 
 
 class _Fork(Function):
