@@ -4,11 +4,12 @@
 // rg_diag_spread / rg_diag_sum): (1,1,7)-tap convolutions between 49 (56 lanes) and 64 channels over 2.1 - 2.4 M voxels, 16 forward /
 // backward-data launches per train step.  igemm4's FLAT path ran them at 180 - 235 TFLOP/s (0.43 - 0.50 ms each): with 64 output
 // columns every activation byte feeds only 64 MACs per tap, and each of the 7 taps fetched it again as 16-row x 64-byte fragments.
-// Both rooflines (578 MB, 120 GFLOP) say ~0.12 ms.  This kernel reaches 0.37 - 0.43 ms (250 - 265 TFLOP/s): the D<->W-exchanged views
-// of ops.conv_kd_as_kw put the tap axis on the slowest memory axis, so the records of a line — and the rows it writes — lie a whole 2-MB plane
-// apart; the arithmetic below is no longer what bounds it.
-// STATUS: parity-green (tests/test_ops_gpu.py::test_line_convolution_kernel) but NOT the default: per launch it is 12 - 15 % faster than the kernels it
-// replaces on three of the four shapes, at step level (same-box A/B, CycleGAN 128^3, 20 steps x 2) 84.3 ms with and without it.
+// Both rooflines (578 MB, 120 GFLOP) say ~0.12 ms.  This kernel reaches 0.37 - 0.43 ms (250 - 265 TFLOP/s) whether the lines are contiguous in
+// memory or a 2-MB plane apart per record: it is bound by its own loop — one wave per SIMD (150 KB of LDS per workgroup), 7 dependent
+// ds_read_b128 per 12 MFMAs, two fragment sets in flight — not by memory.
+// STATUS: parity-green (tests/test_ops_gpu.py::test_line_convolution_kernel) but NOT the default (rg_set_option "RG_LINEW" 1): since ops.py folds
+// (kd, kh) into channels and leaves the KW taps on the memory-fastest axis, igemm4's FLAT path runs these layers at 0.36 ms and the CycleGAN step is
+// 1.1 ms slower with this kernel (same-box A/B, 84.7 against 83.5 ms).
 //
 // Staged in LDS with the records of a line back to back, the K index of an output voxel is a CONTIGUOUS window: 7 taps along W x L lanes =
 // TW * L elements starting at the voxel's record, so
