@@ -498,6 +498,49 @@ def test_line_convolution_kernel(cin, cout, kw, sp, pad, act):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sgn", [1, -1])
+def test_diag_spread_sum_on_exchanged_views_are_exact(sgn):
+    """The (kd, kh) fold of the 7^3 stem / tail (ops.conv3d, ops.conv3d_linear_pair) calls the two maps on D<->W transposed views and asks for
+    D<->W exchanged outputs (strided descriptors on both sides of the kernels).  Exact against numpy indexing, both signs.  (A kernel that walks the
+    passive axis and writes whole records back to back was tried for this layout: 0.6 ms per CycleGAN step SLOWER than the tiled one — removed.)"""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    kh, kw = 3, 5
+    x = rnd((2, 1, 11, 9, 150), 33)                       # logical (n, 1, D, H, W): W will be the passive axis
+    xT = ops.to_cl(x.to(dev)).transpose(2, 4)             # view (n, 1, W, H, D): its D (= W above) is the memory-fastest axis
+    if sgn > 0:
+        oh, ow = 9 - kh + 1, 11 - kw + 1
+    else:
+        oh, ow = 9 + kh - 1, 11 + kw - 1
+    yT = ops._DiagSpread.apply(xT, kh, kw, sgn, oh, ow, True)
+    assert yT.transpose(2, 4).is_contiguous(memory_format=torch.channels_last_3d) or ops.is_cl(yT.transpose(2, 4))
+    xv = x[:, 0].permute(0, 3, 2, 1)                      # (n, W, H, D) as the kernel sees it
+    want = torch.zeros(2, kh * kw, 150, oh, ow)
+    for a in range(kh):
+        for b in range(kw):
+            for hh in range(oh):
+                for ww in range(ow):
+                    sh, sw = hh + sgn * a, ww + sgn * b
+                    if 0 <= sh < 9 and 0 <= sw < 11:
+                        want[:, a * kw + b, :, hh, ww] = xv[:, :, sh, sw]
+    assert torch.equal(yT.float().cpu(), want)
+    z = rnd((2, kh * kw, 11, 9, 150), 34)
+    zT = ops.to_cl(z.to(dev)).transpose(2, 4)
+    sT = ops._DiagSum.apply(zT, kh, kw, sgn, oh, ow, None, True)
+    zv = z.permute(0, 1, 4, 3, 2)
+    acc = torch.zeros(2, 150, oh, ow)
+    for a in range(kh):
+        for b in range(kw):
+            for hh in range(oh):
+                for ww in range(ow):
+                    sh, sw = hh + sgn * a, ww + sgn * b
+                    if 0 <= sh < 9 and 0 <= sw < 11:
+                        acc[:, :, hh, ww] += zv[:, a * kw + b, :, sh, sw]
+    got = sT.float().cpu()[:, 0]
+    assert float((got - acc).abs().max()) <= 2e-2 * max(1.0, float(acc.abs().max()))   # (the sum is rounded to bf16 once)
+
+
+@pytest.mark.gpu
 def test_diag_spread_sum_are_exact_adjoint_gathers():
     """rg_diag_spread / rg_diag_sum (in-plane taps <-> channels) are pure data movement + an fp32 sum: exact against numpy
     indexing on bf16-exact data, both signs."""
