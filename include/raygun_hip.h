@@ -56,7 +56,7 @@ const char* rg_last_error_string(void);
 const char* rg_last_kernel_name(void);
 /* Diagnostic switches (0 = production default): "RG_FM" (forced igemm4 tile height 1..4), "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3",
  * "RG_NO_WLINES", "RG_NO_KWP" (kernel families switched off: the launch falls through to the next candidate), "RG_GEMM5" (the LDS-DMA
- * GEMM of gemm5.hip: -1 off, 1 wherever its 144-column tiling allows, 0 the heuristic), "RG_KWD" (1: the LDS-DMA weight-gradient kernel wgrad_kwd instead of wgrad_kwp — parity-green, not faster: off by default), "RG_LINEW" (1: the line kernel of conv6.hip for (1,1,KW)-tap convolutions between <= 64-lane tensors — parity-green, level with igemm4 / igemm3 at step level: off by default), "RG_DEBUG_BOUNDS"
+ * GEMM of gemm5.hip: -1 off, 1 wherever its 144-column tiling allows, 0 the heuristic), "RG_DEBUG_BOUNDS"
  * (every entry point re-derives the byte extent its kernels may touch from the descriptors and fails with RG_ERR_BAD_SHAPE instead
  * of launching when a workspace / packed operand / view is smaller).  The environment variables of the same names are read ONCE,
  * when the library is loaded; no launch path reads the environment.  Process-wide. */

@@ -18,7 +18,6 @@ bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
 bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p);
 int rg_igemm4_tile_n(int cout);
 bool rg_igemm5_wanted(const CL5& X, const CL5& Y, const rg_conv_params* p, size_t ws_bytes);   // gemm5.hip
-bool rg_linew_wanted(const CL5& X, const CL5& Y, const rg_conv_params* p);                      // conv6.hip
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                      void* workspace, size_t ws_bytes);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
@@ -84,8 +83,7 @@ extern "C" int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const 
     // igemm4 (activations straight into fragments) for 128/144-channel tiles; the kw-reuse kernel keeps the unpadded
     // 128-channel stride-1 layers (787 vs 731 TFLOP/s) and both LDS kernels the narrow tiles
     const bool i3 = rg_igemm3_ok(X, p);
-    if (rg_linew_wanted(X, Y, p)) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0, workspace, ws_bytes))) return rc; }
-    else if (rg_igemm4_ok(X, p) && (!(i3 && rg_igemm4_tile_n(p->cout) == 8) || rg_igemm5_wanted(X, Y, p, ws_bytes))) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0, workspace, ws_bytes))) return rc; }
+    if (rg_igemm4_ok(X, p) && (!(i3 && rg_igemm4_tile_n(p->cout) == 8) || rg_igemm5_wanted(X, Y, p, ws_bytes))) { if ((rc = rg_launch_igemm4(X, Y, w_packed, bias, p, (hipStream_t)s, 0, workspace, ws_bytes))) return rc; }
     else if (i3) rg_launch_igemm3(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     else rg_launch_igemm2(X, Y, w_packed, bias, p, z, (hipStream_t)s);
     RG_CHECK_LAUNCH();

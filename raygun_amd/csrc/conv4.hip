@@ -429,8 +429,6 @@ int rg_launch_igemm_thin(const Igemm4Args& a0, bool check, hipStream_t st);
 bool rg_halo16_ok(const CL5& X, const CL5& Y, const rg_conv_params* p);   // conv5.hip: input halo tile staged in LDS
 int rg_launch_halo16(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, int krow, hipStream_t st);
 bool rg_igemm5_ok(const Igemm4Args& a, bool flat, size_t ws_bytes);
-bool rg_linew_ok(const Igemm4Args& a, bool flat);                      // conv6.hip
-int rg_launch_linew(Igemm4Args& a, bool flat, hipStream_t st);
 int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_t ws_bytes);
 struct Igemm4Batch { int n; long xs, ws, ys; };
 static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
@@ -479,7 +477,6 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   }
   if (flat && a.krow > 48 * 1024) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: K = %d per output row does not fit the piece table", a.krow);
   if (bt && flat) RG_FAIL(RG_ERR_UNSUPPORTED, "gemm_batched: K must be a multiple of 64 lanes");
-  if (!d2s_c && !bt && rg_linew_ok(a, flat != 0)) return rg_launch_linew(a, flat != 0, st);   // taps along W only, <= 64 lanes both sides (conv6.hip)
   if (d2s_c) {   // columns = 8 parity classes x |d2s_c| channels, written interleaved (no split-K: the combine kernel does not shuffle)
     a.cout_lanes = round_up(p->cout, 8);
     a.os[0] = a.os[1] = a.os[2] = 2; a.oo[0] = a.oo[1] = a.oo[2] = 0;

@@ -25,10 +25,10 @@ extern "C" int rg_version(void) { return 101; }
 #include <atomic>
 #include <mutex>
 #include <stdlib.h>
-static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5", "RG_KWD", "RG_LINEW"};
+static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5"};
 static std::atomic<int> g_opt[RG_OPT_COUNT];
 static const bool g_opt_init = [] {   // environment -> switches, once, when the library is loaded
-  for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? ((i == RG_OPT_FM || i == RG_OPT_GEMM5 || i == RG_OPT_KWD) ? atoi(e) : (e[0] && e[0] != '0')) : 0); }
+  for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? ((i == RG_OPT_FM || i == RG_OPT_GEMM5) ? atoi(e) : (e[0] && e[0] != '0')) : 0); }
   return true;
 }();
 int rg_opt(int which) { return which >= 0 && which < RG_OPT_COUNT ? g_opt[which].load(std::memory_order_relaxed) : 0; }
@@ -44,9 +44,9 @@ extern "C" int32_t rg_get_option(const char* name) {
 // Launch errors are otherwise silent (hipLaunchKernelGGL returns nothing): the binding peeks at the runtime's sticky error after
 // every entry point and raises.  0 = no error pending; else the hipError_t, with rg_last_error_string() set.
 extern "C" int rg_hip_status(void) {
-  const hipError_t e = hipPeekAtLastError();
+  const hipError_t e = hipGetLastError();   // reading CLEARS it: one stale error (possibly the caller's own, e.g. torch's) must not fail every later call
   if (e == hipSuccess) return 0;
-  rg_set_error("HIP runtime error pending after %s: %s", g_kname[0] ? g_kname : "(no kernel)", hipGetErrorString(e));
+  rg_set_error("HIP runtime error pending after %s (it may predate this call): %s", g_kname[0] ? g_kname : "(no kernel)", hipGetErrorString(e));
   return (int)e;
 }
 static std::mutex g_latch_mu;

@@ -1012,268 +1012,6 @@ __global__ __launch_bounds__((WA * WB + NPW) * 64, 3) void wgrad_kwp_kernel(Wgra
   }
 }
 
-// ---- wgrad_kwd: the kw-reuse weight gradient with BOTH tiles staged by LDS-DMA and staggered wave groups ------------------------
-// PMC on the U-Net step (profiles/r03a_unet_pmc_mfma.csv): wgrad_kwp_kernel<9,9> keeps the MFMA pipe 39 % busy while its waves sit
-// parked at waits / the barrier 46 % of their cycles — every unit is one lock-step episode (barrier, fragment reads, 27 MFMAs per
-// consumer wave) in which reads and MFMAs of a wave depend on each other, and the loads pass through producer registers.  This kernel
-// is the igemm5 recipe (gemm5.hip) on the weight-gradient problem:
-//   tile      16 FA (a: channels of G, FA = 9 | 8) x 128 (b: channels of X) x TW <= 3 taps; 8 waves, wave w owns b-fragment w x all FA
-//             a-fragments x the W taps = 3 FA accumulators
-//   LDS       G rows are 288 bytes (18 pieces; FA = 8 leaves two unused) stored DENSELY with bits 2 and 3 of the row index
-//             exchanged: the 8 rows {r .. r+3, r+8 .. r+11} a 32-lane half touches in one transposing read then sit at 8 different
-//             offsets mod 8 rows, i.e. tile a 256-byte bank row (72 banks per row).  X rows are 256 bytes with the 32-byte blocks
-//             XOR-swizzled by (row & 3) | (bit 3 of the row) << 2, for every tap shift.  Both permutations are applied to the
-//             SOURCE piece each DMA lane fetches (the DMA writes lane-linearly).
-//   staging   a unit = 32 G rows + (32 + TW - 1) X rows = 18 one-KiB LDS-DMA instructions, no registers, no ds_write, issued by four
-//             PRODUCER waves (8..11, one per SIMD) that also own the unit cursor: with the consumers issuing their own pieces a unit
-//             cost every wave ~130 instructions besides its 27 MFMAs — a wave executes about one instruction per 4-5 cycles, so the
-//             read segment (1100 cycles) outlasted the other group's MFMA cluster (432) and the kernel ran BELOW wgrad_kwp
-//             (708 vs 836 TFLOP/s on 2592 x 2592); 8-stage ring, pieces issued six units ahead, one counted vmcnt per unit
-//   schedule  per unit and consumer wave: [2 FA + 2 TW transposing reads of unit u] lgkmcnt(0) s_barrier [FA TW MFMAs] s_barrier; waves
-//             0-3 and 4-7 (one of each per SIMD) run ONE barrier apart: on every SIMD one wave issues MFMAs while
-//             the other reads fragments
-// Same units / splits / partial-sum layout / row orders (line, flat plane) as wgrad_kwp_kernel.
-// STATUS: parity-green (tests/test_ops_gpu.py::test_wgrad_kwd_lds_dma_weight_gradient) but NOT the default (rg_set_option "RG_KWD" 1
-// enables it).  Measured on MI355X (tools/bench_wgrad.py, same process, random data): 2592 x 2592 @17^3 2.17 ms against 2.14 for
-// wgrad_kwp<9,9>; 2592 -> 3456 2^3 taps 0.88 / 0.92; the 432-channel layers lose 10-25 % (128-channel b-tiles waste 18 % there).
-// Prefetch distances of 2 / 4 / 6 units measure the same, the MFMA pipe is 41 % busy in both kernels (tools/pmc_wgrad.sh): two very
-// different load paths end at the same ~830 TFLOP/s, i.e. the bound is common to both — the consumers' transposing fragment reads
-// (24 per 27 MFMAs and wave) and the fp32 gradient write-out, not the way the tiles reach LDS.
-#define KD_GBYTES 9216
-#define KD_STAGE (9216 + 9216)
-#define KD_NS 8        // LDS ring: stages
-#define KD_TBL_ENTRIES 3072   // flat-plane row table (12 KiB behind the ring)
-typedef int kd_i32x4 __attribute__((ext_vector_type(4)));
-typedef long kd_i64x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void kd_dma(unsigned lds_base, kd_i32x4 rsrc, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void kd_ldtr(long& dst, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); }
-__device__ __forceinline__ int kd_g(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }                 // X: 32-byte block swizzle of a row
-__device__ __forceinline__ int kd_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }      // G: LDS row <-> logical row
-
-template <int FA, int TWM, int KD_AHEAD>
-__global__ __launch_bounds__(768, 3) void wgrad_kwd_kernel(WgradKwArgs p) {
-  const WgradArgs& a = p.w;
-  extern __shared__ __attribute__((aligned(128))) unsigned char kd_lds[];
-  constexpr int TA = FA * 16, TB = 128;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int a0, b0, kh, kd, zsplit;
-  {  // XCD-aware logical order: a-tile fastest, then (kd,kh), then b-tile, then split
-    const int ny = gridDim.y, total = gridDim.x * ny * gridDim.z;
-    int lin = blockIdx.x + gridDim.x * (blockIdx.y + ny * blockIdx.z);
-    { const int q = total / 8, r = total % 8, xcd = lin % 8, idx = lin / 8; lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
-    const int at = lin % p.nta; lin /= p.nta; const int y = lin % ny; lin /= ny; const int bt = lin % p.ntb; zsplit = lin / p.ntb;
-    a0 = at * TA; b0 = bt * TB; kh = y % a.TH; kd = y / a.TH;
-  }
-  const int xrows = 32 + a.TW - 1;
-  const long ubeg = (long)zsplit * p.units_per_split;
-  long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
-  const int nu = (int)(uend - ubeg);
-  const int ntaps = a.TD * a.TH * a.TW;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)kd_lds;
-
-  if (wave >= 8) {
-    // ---------------- producers: waves 8..11 (one per SIMD) own the unit cursor and the 18 LDS-DMA instructions of a unit ----------------
-    const int pw = wave - 8;
-    const int gsw2 = (int)a.gsw * 2, gsh2 = (int)a.gsh * 2, xsw2 = (int)a.xsw * 2;
-    // chunk c = pw + 4 k (k = 0..4): chunks 0..8 are G (64 consecutive pieces of the dense [LDS row][18 pieces] image), 9..17 X
-    // (rows 4 (c - 9) .. + 3, 16 slots each); producers 0 and 1 have five chunks, 2 and 3 four
-    unsigned pv[5]; int prow[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int c = pw + 4 * k;
-      pv[k] = WG_OOB; prow[k] = 0;
-      if (c < 9) {
-        const int q = c * 64 + lane, lrow = q / 18, piece = q - lrow * 18, ch = a0 + piece * 8;
-        prow[k] = kd_swap23(lrow);
-        if (piece < 2 * FA && ch < a.alanes) pv[k] = (unsigned)((p.flat ? 0 : prow[k] * gsw2) + ch * 2);
-      } else if (c < 18) {
-        const int row = (c - 9) * 4 + (lane >> 4), slot = lane & 15;
-        const int piece = (((slot >> 1) ^ kd_g(row)) << 1) | (slot & 1), ch = b0 + piece * 8;
-        if (row < xrows && ch < a.blanes) pv[k] = (unsigned)(row * xsw2 + ch * 2);
-      }
-    }
-    const int rhe = p.flat ? 1 : a.RH;
-    int cwc, crh, crd, cn;
-    {
-      unsigned t = (unsigned)ubeg;
-      cwc = (int)(t % (unsigned)p.wchunks); t /= (unsigned)p.wchunks;
-      crh = (int)(t % (unsigned)rhe); t /= (unsigned)rhe;
-      crd = (int)(t % (unsigned)a.RD); cn = (int)(t / (unsigned)a.RD);
-    }
-    // the cursor is kept incrementally (a wave executes ~1 instruction per 4-5 cycles): line / plane pointers move by precomputed strides
-    const long xs_h = (long)a.rs[1] * a.xsh, xs_d = (long)a.rs[0] * a.xsd;
-    const int c_d = a.tb[0] + kd * a.ts[0], c_h = a.tb[1] + kh * a.ts[1];
-    int id = crd * a.rs[0] + c_d, ih = crh * a.rs[1] + c_h;
-    const bf16_t* gp = a.g + cn * a.gsn + crd * a.gsd + (p.flat ? 0 : crh * a.gsh);
-    const bf16_t* xp = a.x + cn * a.xsn + (long)id * a.xsd + (p.flat ? 0 : (long)ih * a.xsh);
-    const int nrecg = p.flat ? a.RH * gsh2 : a.RW * gsw2, nrecx = p.flat ? a.IH * a.IW * xsw2 : a.IW * xsw2;
-    const int xadd0 = p.flat ? (c_h * a.IW + a.tb[2]) * xsw2 : a.tb[2] * xsw2;
-    // flat-plane order: G row o = 32 cwc + r of a unit is output voxel (h, w) = divmod(o, IW), present iff w < RW and h < RH.  The
-    // byte offset (or "absent") of every row of a plane goes into an LDS table once per workgroup — per unit and G chunk a lane then
-    // needs one ds_read and one add instead of a 14-instruction division / compare / select sequence (the producers are bound by
-    // their instruction rate: without the table 2592 x 2592 ran at 842 TFLOP/s, with the masks switched off at 1042)
-    const bool use_tbl = p.flat && p.wchunks * 32 <= KD_TBL_ENTRIES;
-    unsigned* const tbl = (unsigned*)(kd_lds + KD_NS * KD_STAGE);
-    if (use_tbl) {
-      for (int o = (wave - 8) * 64 + lane; o < p.wchunks * 32; o += 256) {
-        const unsigned h = __umulhi((unsigned)o, p.pmagic), w = (unsigned)o - h * (unsigned)a.IW;
-        tbl[o] = (w < (unsigned)a.RW && h < (unsigned)a.RH) ? h * (unsigned)gsh2 + w * (unsigned)gsw2 : WG_OOB;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                // the table is complete (every wave of the workgroup passes this barrier)
-    const unsigned tbl_lane[3] = {(unsigned)(size_t)(__attribute__((address_space(3))) void*)tbl + (unsigned)prow[0] * 4u,
-                                  (unsigned)(size_t)(__attribute__((address_space(3))) void*)tbl + (unsigned)prow[1] * 4u,
-                                  (unsigned)(size_t)(__attribute__((address_space(3))) void*)tbl + (unsigned)prow[2] * 4u};
-    int nleft = nu;
-    auto issue = [&](int stage) {   // this producer's chunks of the unit under the cursor -> `stage`; advance (past the end: zero records)
-      const bool live = nleft > 0; --nleft;
-      const int w0 = cwc * 32;
-      const bool ok = live && (unsigned)id < (unsigned)a.ID && (p.flat || (unsigned)ih < (unsigned)a.IH);
-      // (descriptor words through readfirstlane: the values ARE wave-uniform, but hipcc must be able to prove it for an "s" operand)
-      auto uni_rsrc = [](const void* base, int nrec) {
-        const unsigned long b = (unsigned long)base;
-        return (i32x4_t){__builtin_amdgcn_readfirstlane((int)(unsigned)b), __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu)),
-                         __builtin_amdgcn_readfirstlane(nrec), 0x00020000};
-      };
-      const i32x4_t rg = uni_rsrc(live ? gp : a.g, live ? nrecg : 0), rx = uni_rsrc(ok ? xp : a.x, ok ? nrecx : 0);
-      const unsigned gadd = p.flat ? 0u : (unsigned)(w0 * gsw2), xadd = (unsigned)(xadd0 + w0 * xsw2);
-      const unsigned sb = lds0 + stage * KD_STAGE + pw * 1024;
-      unsigned toff[3] = {0u, 0u, 0u};
-      if (use_tbl)     // the three G chunks' row offsets of this unit: three reads in flight, ONE wait
-        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)" : "=&v"(toff[0]), "=&v"(toff[1]), "=&v"(toff[2])
-                     : "v"(tbl_lane[0] + (unsigned)(w0 * 4)), "v"(tbl_lane[1] + (unsigned)(w0 * 4)), "v"(tbl_lane[2] + (unsigned)(w0 * 4)) : "memory");
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int c = pw + 4 * k;     // wave-uniform
-        if (c < 9) {
-          unsigned vo = pv[k] + gadd;
-          if (use_tbl) {
-            vo = pv[k] + toff[k < 3 ? k : 0];          // ("absent" = 2^31: the sum stays out of range)
-          } else if (p.flat) {
-            const unsigned o = (unsigned)(w0 + prow[k]), h = __umulhi(o, p.pmagic), w = o - h * (unsigned)a.IW;
-            vo = (w < (unsigned)a.RW && h < (unsigned)a.RH) ? pv[k] + h * (unsigned)gsh2 + w * (unsigned)gsw2 : WG_OOB;
-          }
-          kd_dma(__builtin_amdgcn_readfirstlane(sb + k * 4096), (kd_i32x4)rg, vo);
-        } else if (c < 18) {
-          kd_dma(__builtin_amdgcn_readfirstlane(sb + k * 4096), (kd_i32x4)rx, pv[k] + xadd);   // (chunk 9 starts at byte 9216 = KD_GBYTES)
-        }
-      }
-      if (++cwc == p.wchunks) {
-        cwc = 0;
-        if (p.flat) {
-          ++crd; gp += a.gsd; xp += xs_d; id += a.rs[0];
-          if (crd == a.RD) { crd = 0; id = c_d; gp += a.gsn - a.RD * a.gsd; xp += a.xsn - a.RD * xs_d; }
-        } else {
-          ++crh; gp += a.gsh; xp += xs_h; ih += a.rs[1];
-          if (crh == a.RH) {
-            crh = 0; ih = c_h; gp += a.gsd - a.RH * a.gsh; xp += xs_d - a.RH * xs_h; ++crd; id += a.rs[0];
-            if (crd == a.RD) { crd = 0; id = c_d; gp += a.gsn - a.RD * a.gsd; xp += a.xsn - a.RD * xs_d; }
-          }
-        }
-      }
-    };
-    // everything but my pieces of the KD_AHEAD - 1 youngest units has landed (5 or 4 pieces per unit)
-    auto wait_old = [&]() {
-      if (pw < 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (KD_AHEAD - 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (KD_AHEAD - 1)) : "memory");
-    };
-#pragma unroll
-    for (int u = 0; u < KD_AHEAD; ++u) issue(u);
-    wait_old();                                  // unit 0
-    __builtin_amdgcn_s_barrier();                // (prologue barrier)
-    for (int it = 0; it < nu; ++it) {
-      issue((it + KD_AHEAD) & (KD_NS - 1));      // the stage unit it - 2 was read from: both consumer groups are past it
-      wait_old();                                // unit it + 1: first read two barriers from here
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
-    }
-    __builtin_amdgcn_s_barrier();                // the stagger's closing barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
-
-  // ---------------- consumers: waves 0..7; wave w owns b-fragment w x all FA a-fragments x the W taps ----------------
-  const int grp = wave >> 2;                       // stagger group
-  // fragment read offsets within a stage: lane (fg, fq, fp) supplies row 8 fg + fq (+4 for the second read), 8 bytes at 4 fp
-  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
-  const int rlo = 8 * fg + fq;
-  const unsigned goff = kd_swap23(rlo) * 288 + fp * 8;      // a-fragment i: + 32 i; rows + 4 = LDS rows + 8: + 2304
-  unsigned xlo[TWM], xhi[TWM];
-#pragma unroll
-  for (int t = 0; t < TWM; ++t) {
-    const int r = t + rlo;
-    xlo[t] = KD_GBYTES + r * 256 + ((wave ^ kd_g(r)) << 5) + fp * 8;
-    xhi[t] = KD_GBYTES + (r + 4) * 256 + ((wave ^ kd_g(r + 4)) << 5) + fp * 8;
-  }
-  f32x4 acc[TWM][FA];
-#pragma unroll
-  for (int t = 0; t < TWM; ++t)
-#pragma unroll
-    for (int i = 0; i < FA; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  __builtin_amdgcn_s_barrier();              // (the producers' row table)
-  __builtin_amdgcn_s_barrier();              // (prologue barrier: unit 0 is in LDS)
-  if (grp) __builtin_amdgcn_s_barrier();     // the trailing group runs one barrier behind (matched after the loop)
-
-  for (int it = 0; it < nu; ++it) {
-    const unsigned sbase = lds0 + (it & (KD_NS - 1)) * KD_STAGE;
-    // ---- read segment
-    __builtin_amdgcn_sched_barrier(0);
-    long glo[9], ghi[9], xl[3], xh[3];
-    {
-      const unsigned gb = sbase + goff;
-#define KD_G(i) if constexpr (i < FA) { kd_ldtr<32 * (i)>(glo[i], gb); kd_ldtr<32 * (i) + 2304>(ghi[i], gb); }
-      KD_G(0) KD_G(1) KD_G(2) KD_G(3) KD_G(4) KD_G(5) KD_G(6) KD_G(7) KD_G(8)
-#undef KD_G
-      if constexpr (FA < 9) { glo[8] = 0; ghi[8] = 0; }
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      if (t < TWM) { kd_ldtr<0>(xl[t], sbase + xlo[t < TWM ? t : 0]); kd_ldtr<0>(xh[t], sbase + xhi[t < TWM ? t : 0]); }
-      else { xl[t] = 0; xh[t] = 0; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(glo[0]), "+v"(glo[1]), "+v"(glo[2]), "+v"(glo[3]), "+v"(glo[4]), "+v"(glo[5]), "+v"(glo[6]), "+v"(glo[7]), "+v"(glo[8]),
-                 "+v"(ghi[0]), "+v"(ghi[1]), "+v"(ghi[2]), "+v"(ghi[3]), "+v"(ghi[4]), "+v"(ghi[5]), "+v"(ghi[6]), "+v"(ghi[7]), "+v"(ghi[8]),
-                 "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]) :: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- MFMA cluster
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int t = 0; t < TWM; ++t) {
-      if (t < a.TW) {
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, (kd_i64x2){xl[t], xh[t]});
-#pragma unroll
-        for (int i = 0; i < FA; ++i) acc[t][i] = RG_MFMA16(__builtin_bit_cast(bf16x8, (kd_i64x2){glo[i], ghi[i]}), xf, acc[t][i]);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (!grp) __builtin_amdgcn_s_barrier();    // matches the trailing group's extra barrier
-
-  float* out = a.part + (long)zsplit * a.A * ntaps * a.B;
-#pragma unroll
-  for (int t = 0; t < TWM; ++t) {
-    if (t >= a.TW) continue;
-    const int tap = (kd * a.TH + kh) * a.TW + t;
-    const int bb = b0 + wave * 16 + (lane & 15);
-#pragma unroll
-    for (int i = 0; i < FA; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int aa = a0 + i * 16 + fg * 4 + r;
-        if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[t][i][r];
-      }
-  }
-}
-
 // row order and unit count of the kw-reuse kernel for this problem; false = not eligible
 struct KwGeom { int flat; int wchunks; long units; };
 static bool wgrad_kw_geom(const CL5& G, const CL5& X, const rg_conv_params* p, KwGeom* o) {
@@ -1299,7 +1037,6 @@ static int wgrad_kw_kind(const CL5& G, const CL5& X, const rg_conv_params* p, in
   if (fa == 9 && fb == 9 && p->T[2] <= 3) return 1;
   if (fa == 4 && fb == 4 && p->T[2] <= 8) return 2;
   if (fa == 8 && fb == 8 && p->T[2] <= 4) return 3;
-  if (fa == 9 && fb == 8 && p->T[2] <= 3) return 11;   // wgrad_kwd_kernel<9, .>
   if (p->T[2] == 3) {  // the 72/84/504-channel U-Net levels and mixed tiles: one wave group per kw tap
     if (fa == 5 && fb == 5) return 4;
     if (fa == 9 && fb == 5) return 5;
@@ -1325,13 +1062,6 @@ static int pick_f(int lanes) {
 
 static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int* fa, int* fb, int* nsplit, long* rows_per_split) {
   *fa = pick_f(G.lanes); *fb = pick_f(X.lanes);
-  {  // wide layers on the LDS-DMA kw-reuse kernel (wgrad_kwd_kernel): 144- or 128-channel a-tiles x 128-channel b-tiles
-    KwGeom kg0;
-    if (rg_opt(RG_OPT_KWD) > 0 && *fa >= 8 && *fb >= 8 && p->T[2] <= 3 && wgrad_kw_geom(G, X, p, &kg0)) {
-      *fb = 8;
-      if (*fa == 9 && G.lanes % 144 && round_up(G.lanes, 128) < round_up(G.lanes, 144)) *fa = 8;
-    }
-  }
   const long M = (long)G.N * p->R[0] * p->R[1] * p->R[2];
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
@@ -1345,7 +1075,7 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
     // Kernels with several workgroups per CU: 768 (measured on the whole U-Net step, so that the partial-sum traffic and the
     // reduction passes count: 1536 -> 29.96 ms, 1024 -> 29.68, 768 -> 29.37, 512 -> 29.46; 256 starves the thin tiles: 29.1 vs 27.8).
     long ns = 768 / tl;
-    if ((kind == 1 || kind == 3 || kind == 11) && p->T[2] <= 3) {
+    if ((kind == 1 || kind == 3) && p->T[2] <= 3) {
       // producer-wave kernels, ONE workgroup per CU: 1, 2 or 3 rounds by a cost model — a round costs its units (~0.9 us each)
       // plus ~6 us of prologue / epilogue, every split writes and re-reads one fp32 copy of the gradient tile set (~3.5 TB/s
       // each way).  CycleGAN's 128 -> 128 ResNet-block layers at 32^3 (9 tiles, 1024 units, 1.8 MB of gradient): 85 splits
@@ -1515,24 +1245,7 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
       hipLaunchKernelGGL((wgrad_kwp_kernel<9, 9, 3, 3, 3, 3>), grid, dim3(768), 0, st, ka);
     } else if (kind == 1) hipLaunchKernelGGL((wgrad_kw_kernel<9, 9, 3, 3, 1, 3, false>), grid, dim3(576), 0, st, ka);
     else if (kind == 2) hipLaunchKernelGGL((wgrad_kw_kernel<4, 4, 2, 2, 2, 8, true>), grid, dim3(512), 0, st, ka);
-    else if ((kind == 3 || kind == 11) && a.TW <= 3 && rg_opt(RG_OPT_KWD) > 0) {
-      static rg_device_latch attr_kwd;
-      constexpr int LDSB = KD_NS * KD_STAGE + KD_TBL_ENTRIES * 4;
-      rg_once_per_device(&attr_kwd, [] {
-#define KD_ATTR(F, T, A) hipFuncSetAttribute((const void*)wgrad_kwd_kernel<F, T, A>, hipFuncAttributeMaxDynamicSharedMemorySize, KD_NS * KD_STAGE + KD_TBL_ENTRIES * 4);
-        KD_ATTR(8, 3, 6) KD_ATTR(8, 2, 6) KD_ATTR(9, 3, 6) KD_ATTR(9, 2, 6) KD_ATTR(9, 3, 2) KD_ATTR(9, 3, 4)
-#undef KD_ATTR
-      });
-      const int twm = a.TW <= 2 ? 2 : 3;
-      rg_set_kernel_name("wgrad_kwd_kernel<%d,%d>", fa, twm);
-      const int ahead = rg_opt(RG_OPT_KWD);    // (experiments: 2 / 4 units ahead instead of 6, FA 9 and 3 taps only)
-      if (fa == 9 && twm == 3 && ahead == 2) hipLaunchKernelGGL((wgrad_kwd_kernel<9, 3, 2>), grid, dim3(768), LDSB, st, ka);
-      else if (fa == 9 && twm == 3 && ahead == 4) hipLaunchKernelGGL((wgrad_kwd_kernel<9, 3, 4>), grid, dim3(768), LDSB, st, ka);
-      else if (fa == 9 && twm == 3) hipLaunchKernelGGL((wgrad_kwd_kernel<9, 3, 6>), grid, dim3(768), LDSB, st, ka);
-      else if (fa == 9) hipLaunchKernelGGL((wgrad_kwd_kernel<9, 2, 6>), grid, dim3(768), LDSB, st, ka);
-      else if (twm == 3) hipLaunchKernelGGL((wgrad_kwd_kernel<8, 3, 6>), grid, dim3(768), LDSB, st, ka);
-      else hipLaunchKernelGGL((wgrad_kwd_kernel<8, 2, 6>), grid, dim3(768), LDSB, st, ka);
-    } else if (kind == 3 && a.TW <= 3 && !rg_opt(RG_OPT_NO_KWP)) {
+    else if (kind == 3 && a.TW <= 3 && !rg_opt(RG_OPT_NO_KWP)) {
       rg_set_kernel_name("wgrad_kwp_kernel<%d,%d>", fa, fb);
       hipLaunchKernelGGL((wgrad_kwp_kernel<8, 8, 2, 4, 3, 4>), grid, dim3(768), 0, st, ka);
     } else if (kind == 3) hipLaunchKernelGGL((wgrad_kw_kernel<8, 8, 2, 4, 1, 4, true>), grid, dim3(512), 0, st, ka);

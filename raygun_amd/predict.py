@@ -63,6 +63,7 @@ def _to_destination(out, dtype, on_device=False):
 
 
 FALLBACK_BLOCKS = []   # block indices the f16 runner re-ran with bf16 storage (diagnostics; appended per call)
+NONFINITE_BLOCKS = []  # block indices whose output is inf / NaN even with bf16 storage: stored as the reference stores them, and reported
 
 
 @torch.no_grad()
@@ -83,7 +84,8 @@ def predict_volume(model, source, input_shape=None, output_shape=None, read_size
     config U's affinities land within 1e-3 relative L2 of the fp32 reference; same kernel speed) or "bf16" (the
     training type).  RAYGUN_AMD_PREDICT_PRECISION overrides the default.  Half's largest value is 65504: a block whose f16 run
     produces a non-finite output (fp32 and bf16 would not overflow there) is predicted again with bf16 storage and logged
-    (`predict.FALLBACK_BLOCKS`); with bf16 storage a non-finite output raises FloatingPointError."""
+    (`predict.FALLBACK_BLOCKS`); a block that is non-finite with bf16 storage as well is the network's own inf / NaN: it is stored as the
+    reference stores it (worker.py:133-149), recorded in `predict.NONFINITE_BLOCKS` and logged (RAYGUN_AMD_PREDICT_STRICT=1: FloatingPointError)."""
     precision = precision or os.environ.get("RAYGUN_AMD_PREDICT_PRECISION", "f16")
     with ops.precision(precision):
         return _predict_volume(model, source, input_shape, output_shape, read_size, crop, ndims, scaleShift_input, out_dtypes,
@@ -220,17 +222,23 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         # with a non-finite output is predicted again with bf16 storage — its destination region is simply written a second time
         bad = [bi for bi, ok in zip(mine, torch.stack(flags).tolist()) if not ok] if flags else []
         if bad:
-            if ops.storage_dtype() == torch.bfloat16:
-                raise FloatingPointError(f"raygun_amd.predict: non-finite network output in {len(bad)} block(s) with bf16 storage "
-                                         f"(first: block {bad[0]} at {blocks[bad[0]]})")
             import logging
-            logging.getLogger("raygun_amd.predict").warning(
-                "non-finite output in %d of %d block(s) with f16 storage (half's range is 65504): re-running them with bf16 storage", len(bad), len(mine))
-            with ops.precision("bf16"):
-                again = [run_block(bi, None if resident else fetch(bi)) for bi in bad]
-            if not all(torch.stack(again).tolist()):
-                raise FloatingPointError("raygun_amd.predict: non-finite network output with bf16 storage as well")
-            FALLBACK_BLOCKS.extend(bad)
+            log = logging.getLogger("raygun_amd.predict")
+            if ops.storage_dtype() != torch.bfloat16:
+                log.warning("non-finite output in %d of %d block(s) with f16 storage (half's range is 65504): re-running them with bf16 storage", len(bad), len(mine))
+                with ops.precision("bf16"):
+                    again = [run_block(bi, None if resident else fetch(bi)) for bi in bad]
+                FALLBACK_BLOCKS.extend(bad)
+                bad = [bi for bi, ok in zip(bad, torch.stack(again).tolist()) if not ok]
+            if bad:
+                # bf16 has fp32's range: the network itself produced inf / NaN.  The reference stores what it got (worker.py:133-149: float
+                # destinations keep the value, integer ones the clamped product) — so do we: the blocks are recorded and reported, the other
+                # blocks' work is not thrown away.  RAYGUN_AMD_PREDICT_STRICT=1 turns the report into an error.
+                NONFINITE_BLOCKS.extend(bad)
+                msg = f"raygun_amd.predict: non-finite network output in {len(bad)} block(s) with bf16 storage (first: block {bad[0]} at {blocks[bad[0]]})"
+                if os.environ.get("RAYGUN_AMD_PREDICT_STRICT", "0") == "1":
+                    raise FloatingPointError(msg)
+                log.warning(msg + "; stored as the reference stores it (see predict.NONFINITE_BLOCKS)")
     except BaseException:  # a failing block must not leave the download / prefetch threads behind
         if state["drain"] is not None:
             try:

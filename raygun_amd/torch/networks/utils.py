@@ -32,30 +32,40 @@ def set_norm_mode(net, mode="train"):
         net.eval()
 
 
-def init_weights(net, init_type="normal", init_gain=0.02, nonlinearity="relu"):
-    """utils.py:45-81 — every Conv*/Linear weight; bias <- 0; BatchNorm2d weight ~ N(1, gain)."""
+# init_type -> in-place initialiser of a weight tensor, given the gain (the reference's four schemes, utils.py:51-63)
+_WEIGHT_INIT = {
+    "normal": lambda w, gain: init.normal_(w, 0.0, gain),
+    "xavier": lambda w, gain: init.xavier_normal_(w, gain=gain),
+    "kaiming": lambda w, gain: init.kaiming_normal_(w, a=0, mode="fan_in"),
+    "orthogonal": lambda w, gain: init.orthogonal_(w, gain=gain),
+}
 
-    def init_func(m):
-        classname = m.__class__.__name__
-        if hasattr(m, "weight") and (classname.find("Conv") != -1 or classname.find("Linear") != -1):
-            if init_type == "normal":
-                init.normal_(m.weight.data, 0.0, init_gain)
-            elif init_type == "xavier":
-                init.xavier_normal_(m.weight.data, gain=init_gain)
-            elif init_type == "kaiming":
-                init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
-            elif init_type == "orthogonal":
-                init.orthogonal_(m.weight.data, gain=init_gain)
-            else:
-                raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
-            if hasattr(m, "bias") and m.bias is not None:
-                init.constant_(m.bias.data, 0.0)
-        elif classname.find("BatchNorm2d") != -1:
-            init.normal_(m.weight.data, 1.0, init_gain)
-            init.constant_(m.bias.data, 0.0)
+
+def _is_linear_map(module):
+    """The layers the reference re-initialises: any class whose NAME contains Conv or Linear (so subclasses such as hipnn.Conv3d and
+    ConvTranspose3d count) and that owns a weight."""
+    name = type(module).__name__
+    return ("Conv" in name or "Linear" in name) and getattr(module, "weight", None) is not None
+
+
+def init_weights(net, init_type="normal", init_gain=0.02, nonlinearity="relu"):
+    """utils.py:45-81: weights of every Conv* / Linear layer drawn by `init_type`, their biases zeroed; BatchNorm2d gets weight ~ N(1, gain)
+    and bias 0; an unknown `init_type` raises NotImplementedError at the first such layer, as the reference does.  Prints the reference's line."""
+    def visit(module):
+        if _is_linear_map(module):
+            try:
+                draw = _WEIGHT_INIT[init_type]
+            except KeyError:
+                raise NotImplementedError("initialization method [%s] is not implemented" % init_type) from None
+            draw(module.weight.data, init_gain)
+            if getattr(module, "bias", None) is not None:
+                module.bias.data.zero_()
+        elif "BatchNorm2d" in type(module).__name__:
+            init.normal_(module.weight.data, 1.0, init_gain)
+            module.bias.data.zero_()
 
     print("initialize network with %s" % init_type)
-    net.apply(init_func)
+    net.apply(visit)
     from ... import ops
     ops.invalidate_packed(net)  # the writes above go through .data: they do not bump the version the packed-operand caches key on
 

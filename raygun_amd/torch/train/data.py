@@ -61,17 +61,25 @@ class MTLSDCropBatches:
     `min_masked` of the label mask when the config asks for it), raw normalised to [0, 1] then scaled to [-1, 1]
     (gp.Normalize + IntensityScaleShift(2, -1), :146,:132), and on the GPU: gt_lsds / lsds_weights (AddLocalShapeDescriptor),
     gt_affs (AddAffinities over the label crop grown by the neighbourhood's extent and the LSD context) and affs_weights
-    (BalanceLabels over the affinity mask).  Yields the names MTLSDModel.forward / WeightedMSELoss_MTLSD.forward take."""
+    (BalanceLabels over the affinity mask).  Yields the names MTLSDModel.forward / WeightedMSELoss_MTLSD.forward take.
+
+    Several sources are JOINED as the reference joins them (io/MTLSDDataPipe.py:163-164, gp.MergeProvider): each source contributes the
+    datasets it names, together they form one provider, and a dataset named by two sources is an error (gunpowder asserts the same)."""
 
     def __init__(self, sources, input_shape, output_shape, neighborhood, voxel_size, lsd_kwargs, batch_size, device, seed=42, rank=0,
                  random_location_kwargs=None):
         from ... import zarrio
-        self.srcs = []
+        merged = {}
         for src in (sources if isinstance(sources, (list, tuple)) else [sources]):
-            a = {k: zarrio.open_ds(src["path"], src[k]) for k in ("raw", "labels", "labels_mask") if k in src}
-            if "raw" not in a or "labels" not in a:
-                raise ValueError("an MTLSD source needs at least 'raw' and 'labels' dataset names")
-            self.srcs.append(a)
+            for k in ("raw", "labels", "labels_mask"):
+                if k in src:
+                    if k in merged:
+                        raise ValueError(f"MTLSD sources: {k!r} is provided by more than one source (the reference merges its sources with "
+                                         "gp.MergeProvider, which takes every array from exactly one provider)")
+                    merged[k] = zarrio.open_ds(src["path"], src[k])
+        if "raw" not in merged or "labels" not in merged:
+            raise ValueError("the MTLSD sources must name at least a 'raw' and a 'labels' dataset")
+        self.srcs = [merged]
         self.inp, self.out = tuple(int(v) for v in input_shape), tuple(int(v) for v in output_shape)
         self.nb = np.asarray(neighborhood, dtype=np.int32).reshape(-1, 3)
         self.vs = tuple(float(v) for v in voxel_size)
@@ -118,7 +126,7 @@ class MTLSDCropBatches:
         if self.lsd:
             # (the sub-sampling grid is anchored at the crop's origin, as it is at the batch's label array in the reference)
             b["gt_lsds"] = T.lsd_targets(lab, self.lsd["sigma"], self.vs, int(self.lsd.get("downsample", 1)), off, self.out)
-            fg = (lab[tuple(slice(o, o + s) for o, s in zip(off, self.out))] > 0).to(torch.float32)
+            fg = (lab[tuple(slice(o, o + s) for o, s in zip(off, self.out))] != 0).to(torch.float32)   # lsd's mask: labels != 0, on the uncast ids
             b["lsds_weights"] = fg[None].expand(10, *self.out).contiguous()
         return b
 

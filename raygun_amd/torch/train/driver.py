@@ -44,6 +44,10 @@ def train_step(model, loss_fn, optimizer, batch, grad_sync=None, scaler=None):
         outs = outs if isinstance(outs, (tuple, list)) else (outs,)
         named = dict(zip(model.output_arrays, outs))
         pool = {**batch, **named}
+        missing = [k for k in _names(loss_fn.forward) if k not in pool]
+        if missing:
+            raise KeyError(f"raygun_amd.train_step: the loss takes {missing}, which neither the batch nor the model provides "
+                           f"(an MTLSD config without `lsd_kwargs` yields no gt_lsds / lsds_weights); batch keys: {sorted(batch)}")
         loss = loss_fn(*[pool[k] for k in _names(loss_fn.forward)])
     (scaler.scale(loss) if scaler is not None and not own_step else loss).backward()  # a no-op for the CycleGAN losses, which own their backward+step (LinkCycleLoss.py:173)
     if grad_sync is not None and isinstance(optimizer, torch.optim.Optimizer):

@@ -146,6 +146,8 @@ def blosc_encode(raw, cfg):
     shuffle = ts > 1 and int(cfg.get("shuffle", 1)) != 0
     bs = int(cfg.get("blocksize", 0)) or (1 << 18)
     bs = max(ts, bs // ts * ts)
+    if n > 0:   # c-blosc clamps the block size to the buffer (a decompressor may reject a header whose blocksize exceeds nbytes)
+        bs = min(bs, max(ts, n // ts * ts))
     if n >= (1 << 31) - 16 - 4 * ((n + bs - 1) // bs + 1):
         raise ValueError("blosc: chunk too large for one frame")
     nblocks = (n + bs - 1) // bs if n else 0

@@ -68,10 +68,10 @@ def test_blockwise_equals_whole_volume():
 
 
 @pytest.mark.gpu
-def test_f16_overflow_falls_back_to_bf16_per_block():
+def test_f16_overflow_falls_back_to_bf16_per_block(monkeypatch):
     """IEEE-half storage (the block runner's default) overflows at 65504 where the fp32 reference and bf16 stay finite: a block
     with a non-finite output is predicted again with bf16 storage (and recorded), so the result equals the bf16 run; with bf16
-    storage itself a non-finite output raises."""
+    storage itself a non-finite output is stored as the reference stores it and recorded (strict mode: raises)."""
     from raygun_amd.torch.networks import UNet
     dev = torch.device("cuda")
     net = UNet(input_nc=1, ngf=4, fmap_inc_factor=2, downsample_factors=[(2, 2, 2)], constant_upsample=True)
@@ -93,6 +93,10 @@ def test_f16_overflow_falls_back_to_bf16_per_block():
     assert np.array_equal(got[0][:, redone], ref[0][:, redone])
     sd[last] = sd[last] * float("inf")
     net.load_state_dict(sd)
+    del P.NONFINITE_BLOCKS[:]
+    bad, n = P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, precision="bf16")   # stored like the reference, and reported
+    assert len(P.NONFINITE_BLOCKS) == n and not np.isfinite(bad[0]).all()
+    monkeypatch.setenv("RAYGUN_AMD_PREDICT_STRICT", "1")
     with pytest.raises(FloatingPointError):
         P.predict_volume(net, vol, input_shape=[36] * 3, output_shape=[20] * 3, precision="bf16")
 

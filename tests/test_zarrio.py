@@ -253,6 +253,7 @@ def test_blosc_encode_frames(tmp_path, dtype, cfg):
         assert f[0] == 2 and f[1] == 1 and f[3] == ts
         nbytes, bsize, cbytes = (int.from_bytes(f[4 + 4 * i:8 + 4 * i], "little") for i in range(3))
         assert nbytes == len(payload) and cbytes == len(f) and bsize % ts == 0 and (f[2] >> 5) == 3 and f[2] & 0x10
+        assert nbytes == 0 or bsize <= max(nbytes, ts), "header block size beyond the buffer (c-blosc clamps it; its decompressor checks)"
         assert zarrio.blosc_decode(f) == payload
         if payload is smooth:
             assert len(f) < len(payload) // 2 and not f[2] & 0x2
@@ -271,6 +272,12 @@ def test_blosc_encode_frames(tmp_path, dtype, cfg):
     assert np.array_equal(zarrio.open(root)[...], vol)
     raw = open(os.path.join(root, "0.0.0"), "rb").read()
     assert raw[0] == 2 and int.from_bytes(raw[4:8], "little") == 4 * 20 * 16 * ts       # a Blosc frame of one whole chunk
+    try:   # pinned against the real codec wherever numcodecs is installed (it is not in this image)
+        from numcodecs import Blosc
+    except ImportError:
+        return
+    for payload in (smooth, noisy, smooth[:ts * 3]):
+        assert bytes(Blosc().decode(zarrio.blosc_encode(payload, {**cfg, "_typesize": ts}))) == payload
 
 
 @pytest.mark.parametrize("comp", ["default", None, {"type": "bzip2", "blockSize": 9}, {"type": "xz", "preset": 6}, {"type": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}])
