@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16"], help="unet workload: 16-bit storage type (f16 = IEEE half + dynamic loss scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="unet workload: do not also time the CycleGAN 128^3 step")
-    ap.add_argument("--secondary-dp", action="store_true", help="with --gpus N > 1: time the CycleGAN step data-parallel as well (default: N = 1 only, "
-                    "so that the scaling runs carry one workload and one set of collectives)")
+    ap.add_argument("--secondary-dp", action="store_true", help="(default since round 4: every --gpus N run times the CycleGAN step data-parallel as well — "
+                    "BASELINE config 4 is 'DDP CycleGAN + UNet'; the flag is accepted and ignored)")
+    ap.add_argument("--replicas", action="store_true", help="config5 / predict / segment with --gpus N: one private volume per GPU (no exchange) instead of ONE "
+                    "global volume sharded over the ranks")
     ap.add_argument("--cpu-size", type=int, default=0)
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N without a launcher: seconds before the supervised ranks are terminated")
     return ap.parse_args()
@@ -213,7 +215,8 @@ def cpu_baseline(workload, size):
         ga = torch.from_numpy(synth.uniform((1, 3, out, out, out), 142, 0, 1))
         gl = torch.from_numpy(synth.uniform((1, 10, out, out, out), 242, 0, 1))
         opt = torch.optim.Adam(m.parameters(), lr=0.5e-4)
-        dt, n, warm = timed_median(lambda: O.mtlsd_step(m, lf, opt, raw, gl, torch.ones_like(gl), ga, torch.ones_like(ga)), budget_s=60.0)
+        # 1 warm-up + >= 3 timed steps (~26 s each on 128 cores: ~110 s of the driver's 600)
+        dt, n, warm = timed_median(lambda: O.mtlsd_step(m, lf, opt, raw, gl, torch.ones_like(gl), ga, torch.ones_like(ga)), budget_s=170.0)
         return dict(value=size ** 3 / dt / 1e6, unit="Mvoxels/s", cores=cores, kind="port", cpu=cpu,
                     sample=f"train step (fwd+loss+bwd+Adam) of the CPU restatement at {size}^3 (torch {torch.__version__} fp32, oneDNN): "
                            f"1 warm-up step ({warm:.1f} s) + median of {n} steps = {dt:.1f} s")
@@ -363,24 +366,55 @@ def main_aux(a, rank, local, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def config5_volume(gshape, z0, z1, dev, seed=77):
+    """Planes [z0, z1) of the synthetic uint8 volume of --workload config5: smooth blobs + 60 grey levels of noise, both pure functions of the GLOBAL
+    voxel coordinate (an integer hash for the noise), so that every rank generates exactly its part of ONE volume."""
+    Z, Y, X = gshape
+    y = torch.arange(Y, device=dev, dtype=torch.float32)
+    x = torch.arange(X, device=dev, dtype=torch.float32)
+    yi, xi = torch.arange(Y, device=dev, dtype=torch.int64)[None, :, None], torch.arange(X, device=dev, dtype=torch.int64)[None, None, :]
+    out = torch.empty((z1 - z0, Y, X), dtype=torch.uint8, device=dev)
+    for a0 in range(z0, z1, 32):
+        a1 = min(z1, a0 + 32)
+        z = torch.arange(a0, a1, device=dev, dtype=torch.float32)
+        blobs = (torch.sin(z / 9.1 + 1)[:, None, None] * torch.sin(y / 11.3)[None, :, None] * torch.sin(x / 8.7 + 1.0)[None, None, :]).abs() > 0.2
+        zi = torch.arange(a0, a1, device=dev, dtype=torch.int64)[:, None, None]
+        h = (zi * 73856093 + seed) ^ (yi * 19349663) ^ (xi * 83492791)
+        h = ((h * 2654435761) >> 11) & 0xFFFF
+        out[a0 - z0:a1 - z0] = (blobs.float() * 140 + 40 + 60 * (h.float() / 65536.0)).clamp_(0, 255).to(torch.uint8)
+    return out
+
+
 def main_config5(a, rank, local, world, dev):
-    """--workload config5 (SURVEY.md 8d config 5 on one GPU per rank, HBM-resident): a synthetic uint8 volume (hash noise + smooth blobs)
+    """--workload config5 (HBM-resident): a synthetic uint8 volume (hash noise + smooth blobs)
     -> block-wise prediction with MTLSDModel(num_affs = 20) in 196^3 -> 104^3 blocks (f16 storage, uint8 affinities left on the device)
     -> rg_mws_prepare -> (slab) mutex watershed, sep 3, strides 10, mask threshold 0.5.  One JSON line: end-to-end seconds, blocks/s,
-    Mvoxels/s and both rooflines (the dominant convolution kernel against the MFMA peak, the Kruskal kernel against HBM).  With N > 1
-    ranks every rank runs the chain on its own volume (replicas: the sharded form — Z parts + one boundary exchange — is
-    segment_slabs(z0, global_shape), exercised by tests/test_multirank_gpu.py)."""
+    Mvoxels/s and both rooflines (the dominant convolution kernel against the MFMA peak, the Kruskal kernel against HBM).
+
+    --gpus N > 1: ONE global volume, as BASELINE config 5 says (reference flow: predict.py:154-170 over the whole dataset, then segment.py:139-230 over
+    the whole affinity array).  pipeline.shard_plan cuts its Z axis on the block grid; every rank generates its planes (+ the read halo of its first /
+    last block row) from the global coordinates, predicts its blocks (no collective), and segments its owned planes through
+    segment_slabs(z0, global_shape) — one neighbour exchange of the boundary zones + an all-gather of the second-level edge records (RCCL).  The
+    labels stay distributed (rank r holds its planes).  Default global volume: 404 x 404 in-plane and 3 block rows of Z per rank (weak scaling:
+    27 blocks per GPU, as the one-GPU default 404^3); `--size S`: the S^3 cube over all ranks (strong scaling — 2048 is BASELINE's).  `--replicas`
+    keeps the round-3 behaviour (one private volume per GPU, no exchange)."""
     import ctypes as C
     from raygun_amd import _lib, ops, pipeline, predict as P
     from raygun_amd.torch.models import MTLSDModel
+    sharded = world > 1 and not a.replicas
     size = a.size or 404
+    gshape = (size,) * 3 if (a.size or not sharded) else (92 + 104 * 3 * world, 404, 404)
     torch.manual_seed(1234)
     with torch.device(dev):
         model = MTLSDModel(num_affs=20).eval()
-    g = torch.Generator(device=dev).manual_seed(77 + rank)
-    r = torch.arange(size, device=dev, dtype=torch.float32)
-    blobs = (torch.sin(r / 9.1 + 1)[:, None, None] * torch.sin(r / 11.3)[None, :, None] * torch.sin(r / 8.7 + 1.0)[None, None, :]).abs() > 0.2
-    vol = (blobs.float() * 140 + 40 + 60 * torch.rand((size,) * 3, generator=g, device=dev)).clamp_(0, 255).to(torch.uint8)
+    if sharded:
+        part = pipeline.shard_plan(gshape, world)[rank]
+        vol = config5_volume(gshape, part["src"][0], part["src"][1], dev)
+        chain_kw = dict(z0=part["src"][0], own=part["own"], global_shape=gshape)
+    else:
+        part = dict(src=(0, gshape[0]), own=(0, gshape[0]), rows=None)
+        vol = config5_volume(gshape, 0, gshape[0], dev, seed=77 + rank)
+        chain_kw = {}
     nblk = len(P.enumerate_blocks(vol.shape, *P.roi_geometry(3, [196] * 3, [104] * 3)))
     from raygun_amd import segment as S
     nbh = torch.as_tensor(S.build_neighborhood().astype("int64"))
@@ -407,21 +441,21 @@ def main_config5(a, rank, local, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize()
     steps, warmup = max(1, min(a.steps, 3)), max(1, min(a.warmup, 1))
-    if size <= 512:
+    if max(gshape) <= 512 and not sharded:
         _, raw_info = pipeline.predict_and_segment(model, vol)       # the raw network output, once: the adversarial case beside the headline
-        raw_case = dict(segment_s=round(raw_info["segment_s"], 3), predict_s=round(raw_info["predict_s"], 3),
-                        note="unshaped output of the random-initialised network (noise around 0.5): adversarial for the Kruskal pass")
+        raw_case = dict(total_s=round(raw_info["total_s"], 3), segment_s=round(raw_info["segment_s"], 3), predict_s=round(raw_info["predict_s"], 3),
+                        note="UNSHAPED output of the random-initialised network (noise around 0.5): adversarial for the Kruskal pass")
     else:
-        raw_case = dict(skipped="the adversarial case grows faster than the volume (7.4 s at 404^3): not run beyond 512^3")
-    model_raw, model_ = model, shaped
+        raw_case = dict(skipped="the unshaped (pure-noise) case is reported by the one-GPU run at <= 512^3 only")
+    model_ = shaped
     for _ in range(warmup):
-        labels, info = pipeline.predict_and_segment(model_, vol)
+        labels, info = pipeline.predict_and_segment(model_, vol, **chain_kw)
     barrier()
     ops.profile_start()
     t0 = time.perf_counter()
     tp = ts = 0.0
     for _ in range(steps):
-        labels, info = pipeline.predict_and_segment(model_, vol)
+        labels, info = pipeline.predict_and_segment(model_, vol, **chain_kw)
         tp += info["predict_s"]; ts += info["segment_s"]
     barrier()
     dt = time.perf_counter() - t0
@@ -429,30 +463,52 @@ def main_config5(a, rank, local, world, dev):
     n = _lib.lib().rg_profile_drain(buf, 8 * steps + 1)        # the library bracketed the Kruskal kernel of every mutex-watershed pass
     mws_ms = float(sum(buf[:n])) / steps
     prof = ops.profile_stop()
+    nseg = int(labels.max().item())
+    blocks_all, own_vox = nblk, int(labels.numel())
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, tp, ts], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, tp, ts = (float(v) for v in t.tolist())
+        c = torch.tensor([nblk, own_vox], device=dev, dtype=torch.int64)
+        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
+        blocks_all, own_vox = (int(v) for v in c.tolist())
+        m = torch.tensor([nseg], device=dev, dtype=torch.int64)
+        torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)   # labels are global ranks of first voxels: the largest one is the count
+        nseg = int(m.item())
+        backend = torch.distributed.get_backend()
+        ranks_seen = torch.distributed.get_world_size()
         if rank != 0:
             torch.distributed.destroy_process_group()
             return
+    else:
+        backend, ranks_seen = "none (single process)", 1
     sec = dt / steps
+    voxels = (gshape[0] * gshape[1] * gshape[2]) if sharded else size ** 3 * world
+    assert not sharded or own_vox == voxels, (own_vox, voxels)      # the owned parts tile the global volume
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
     ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
-    hbm = size ** 3 * MWS_BYTES_PER_VOXEL / (mws_ms * 1e-3) / 1e9 if mws_ms else None
+    hbm = labels.numel() * MWS_BYTES_PER_VOXEL / (mws_ms * 1e-3) / 1e9 if mws_ms else None
+    shape_s = "x".join(str(v) for v in gshape)
     res = dict(metric="config 5 end to end: block-wise predict + mutex watershed, seconds per volume", value=round(sec, 4), unit="s", n_gpus=world, steps=steps,
-               warmup=warmup, ms_per_step=round(sec * 1e3, 2), higher_is_better=False, scaling="weak", vs_baseline=None, dtype="f16 storage / f32 keys", data="synthetic",
-               config=dict(workload=f"config5 {size}^3 uint8 volume per GPU resident in HBM: {nblk} blocks 196^3 -> 104^3 through MTLSDModel(20 affinities + 10 LSDs), "
-                                    "uint8 affinities left on the device, rg_mws_prepare + mutex watershed (20 offsets, sep 3, strides 10, mask 0.5)",
-                           parallelism=f"one volume per GPU x{world}"),
-               blocks_per_s=round(nblk * world / (tp / steps), 2), predict_s=round(tp / steps, 4), segment_s=round(ts / steps, 4),
-               mvoxels_per_s=round(size ** 3 * world / sec / 1e6, 2), segments=int(labels.max().item()), raw_network_case=raw_case,
-               affinity_shaping="network output blended 20/80 with a both-voxels-inside-a-blob structure term per offset (see bench.py main_config5.shaped)",
+               warmup=warmup, ms_per_step=round(sec * 1e3, 2), higher_is_better=False, scaling=("strong" if a.size else "weak"), vs_baseline=None,
+               dtype="f16 storage / f32 keys", data="synthetic",
+               config=dict(workload=(f"config5: ONE {shape_s} uint8 volume sharded over {world} ranks on the block grid (pipeline.shard_plan), " if sharded else
+                                     f"config5 {shape_s} uint8 volume per GPU resident in HBM, ") +
+                                    f"{blocks_all} blocks 196^3 -> 104^3 through MTLSDModel(20 affinities + 10 LSDs), uint8 affinities left on the device, "
+                                    "rg_mws_prepare + mutex watershed (20 offsets, sep 3, strides 10, mask 0.5)" +
+                                    ("; first level per rank, one boundary exchange, replicated second level (segment_slabs)" if sharded else ""),
+                           parallelism=(f"one volume over {world} GPUs: Z parts of {[p['own'][1] - p['own'][0] for p in pipeline.shard_plan(gshape, world)]} planes"
+                                        if sharded else f"one volume per GPU x{world}"), global_shape=list(gshape)),
+               ranks_seen=ranks_seen, backend=backend,
+               blocks_per_s=round(blocks_all * (1 if sharded else world) / (tp / steps), 2), predict_s=round(tp / steps, 4), segment_s=round(ts / steps, 4),
+               mvoxels_per_s=round(voxels / sec / 1e6, 2), segments=nseg, raw_network_case=raw_case,
+               affinity_shaping="SHAPED input: network output blended 20/80 with a both-voxels-inside-a-blob structure term per offset (bench.py main_config5.shaped); "
+                                "the unshaped figure is `raw_network_case`",
                roofline=dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
                              launches_per_step=dom[1]["launches"] // steps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4)),
                roofline_segment=dict(bound="hbm", kernel="mws_rounds_kernel", achieved=None if hbm is None else round(hbm, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                      frac=None if hbm is None else round(hbm / HBM_PEAK_GBS, 5), traffic=None, ms_per_volume=round(mws_ms, 3),
-                                     note="88 B/voxel algorithmic; round-latency bound (dependency-ordered union-find), see --workload segment"))
+                                     note="rank 0's part; 88 B/voxel algorithmic; round-latency bound (dependency-ordered union-find), see --workload segment"))
     print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -498,7 +554,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
     from raygun_amd import ops, parallel
     with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
         step, info = build_unet(dev, size, seed=rank, precision=precision) if workload == "unet" else build_cyclegan(dev, size, seed=rank)
-    sync = parallel.GradSync(prescaled=(workload == "unet"))
+    sync = parallel.GradSync(prescaled=(workload == "unet"), timing=world > 1)   # algo: RAYGUN_AMD_GRADSYNC = allreduce (default) | rs_ag
     # The interpreter's full (generation-2) garbage collection walks every object the imports created — ~70 ms on this image — and,
     # landing in a timed step while the host is less than that ahead of the GPU, shows up as one 80-ms step (tools/step_trend.py).
     # Long-lived objects go to the permanent generation, as raygun_amd's Trainer does before its loop.
@@ -538,6 +594,14 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
     barrier()
     dt = time.perf_counter() - t0
     prof = ops.profile_stop()
+    waits = sync.wait_ms() if world > 1 else []   # per GradSync call: what the compute stream waited for the gradient exchange (not hidden by backward)
+    comm = dict(ranks_seen=torch.distributed.get_world_size() if world > 1 else 1,
+                backend=(torch.distributed.get_backend() + (" (RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()) + ")"
+                                                           if torch.distributed.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
+                gradsync_algo=sync.algo, gradsync_calls_per_step=round(len(waits) / max(1, steps), 2),
+                allreduce_wait_ms_per_step=round(sum(waits) / max(1, steps), 3) if waits else 0.0,
+                allreduce_wait_ms_max_step=round(max(waits), 3) if waits else 0.0,
+                collectives_last_step=dict(sync.stats))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -581,7 +645,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
                **(dict(optimizer_ms=round(sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3),
                        fwd_bwd_ms=round(ms - sum(a.elapsed_time(b) for a, b in opt_marks) / len(opt_marks), 3)) if opt_marks else {}),
                executed_frac_of_mfma_peak=round(executed / (dt / steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
-               roofline=roofline, kernels=kernels)
+               comm=comm, roofline=roofline, kernels=kernels)
     return res
 
 
@@ -620,7 +684,7 @@ def main():
             res["f16_storage"]["note"] = ("same network, step and sizes with f16 storage + dynamic loss scaling (raygun_amd/amp.py); optimizer_ms "
                                           "includes the gradient inf check and its 4-byte host read")
         del h
-    if a.workload == "unet" and not a.no_secondary and (world == 1 or a.secondary_dp):
+    if a.workload == "unet" and not a.no_secondary:
         # BASELINE's metric string has a second half — "CycleGAN 128^3 train-step ms" (config 2; with N > 1: config 4): timed in
         # the same run, after the U-Net's memory is released, and reported inside the same JSON line
         import gc
@@ -633,7 +697,7 @@ def main():
                                     algorithmic_tflops=sec["step_tflops"], executed_tflops=sec["executed_tflops"],
                                     executed_frac_of_mfma_peak=sec["executed_frac_of_mfma_peak"],
                                     roofline={k: sec["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms")}
-                                    if sec["roofline"] else None,
+                                    if sec["roofline"] else None, comm=sec["comm"], n_gpus=sec["n_gpus"],
                                     kernel_launches_per_step=sum(k["launches"] for k in sec["kernels"].values()))
     if rank != 0:
         if world > 1:

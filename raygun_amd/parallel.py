@@ -102,6 +102,7 @@ def _flat(g):
 
 BUCKET_BYTES = 32 << 20     # small gradients travel together in flat fp32 buckets of at most this size
 SMALL_BYTES = 1 << 20       # a gradient below this size is "small"
+RS_MIN_BYTES = 64 << 20     # algo "rs_ag": gradients from this size on travel as reduce-scatter + all-gather
 
 
 class GradSync:
@@ -124,17 +125,29 @@ class GradSync:
     >= 11.9 ms if a single ring binds it to one link; CycleGAN generators 0.2 GB + discriminators 0.09 GB: 0.3 / 2.3 ms and
     0.15 / 1.0 ms.  Against a 29-ms U-Net step the exchange hides behind the backward pass in either case."""
 
-    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, small_bytes=SMALL_BYTES, prescaled=False, force=False):
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES, small_bytes=SMALL_BYTES, prescaled=False, force=False, algo=None, rs_min_bytes=RS_MIN_BYTES,
+                 timing=False):
         self.group = group
         self.force = bool(force)   # run the collectives in a one-rank group too (tests: the RCCL code path on a one-GPU box)
         # prescaled: the caller already scaled the loss (its backward seed) by 1 / world size, so the SUM is the mean and the pass
         # that divides a gigabyte of gradients afterwards (0.45 ms per U-Net step) is not needed
         self.prescaled = bool(prescaled)
         self.bucket_bytes, self.small_bytes = int(bucket_bytes), int(small_bytes)
-        self._pending = {}   # id(param) -> (grad tensor, work handle)   large gradients started by a hook
+        # algo "allreduce" (default): one dist.all_reduce per large gradient, RCCL chooses ring / tree / mesh itself.  "rs_ag": gradients of at least
+        # `rs_min_bytes` go as an explicit reduce-scatter + all-gather pair over the same buffer (SURVEY.md 8e: every GPU owns 1 / N of the sum, each
+        # half moves (N-1)/N S over all seven xGMI links at once) — the same sum, rank-identical results; RAYGUN_AMD_GRADSYNC selects it from outside.
+        self.algo = algo or os.environ.get("RAYGUN_AMD_GRADSYNC", "allreduce")
+        if self.algo not in ("allreduce", "rs_ag"):
+            raise ValueError(f"raygun_amd.GradSync: algo {self.algo!r} (allreduce | rs_ag)")
+        self.rs_min_bytes = int(rs_min_bytes)
+        self._pending = {}   # id(param) -> (grad tensor, work handles)  large gradients started by a hook
         self._small = {}     # id(param) -> grad tensor                   small gradients seen by a hook, bucketed at call time
         self._hooks = []
-        self.stats = dict(large=0, buckets=0, small=0)   # collectives issued by the last call
+        self.stats = dict(large=0, buckets=0, small=0, rs_ag=0)   # collectives issued by the last call
+        # timing: how long the compute stream (RCCL: device time between two events around the waits) or the host (gloo) waited for the
+        # exchange in each call — what the backward pass did NOT hide.  Read with wait_ms().
+        self.timing = bool(timing)
+        self._waits = []
 
     def attach(self, params):
         if world_size() == 1 and not self.force:
@@ -152,6 +165,34 @@ class GradSync:
     def _is_small(self, g):
         return g.numel() * g.element_size() < self.small_bytes
 
+    def _reduce_large(self, g):
+        """Start the exchange of one large gradient; returns its work handles (waited for in __call__)."""
+        flat = _flat(g).reshape(-1)
+        ws = dist.get_world_size(self.group)
+        n = flat.numel()
+        if self.algo != "rs_ag" or n * flat.element_size() < self.rs_min_bytes or n < ws or ws == 1:
+            return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        rank = dist.get_rank(self.group)
+        m = n // ws
+        main, tail = flat[:m * ws], flat[m * ws:]
+        shard = main[rank * m:(rank + 1) * m]
+        handles = []
+        if dist.get_backend(self.group) == "nccl":
+            # RCCL's in-place forms (receive buffer = send buffer + rank * count); both calls are queued on the communicator's stream in order
+            handles.append(dist.reduce_scatter_tensor(shard, main, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            handles.append(dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True))
+        else:   # gloo runs asynchronous work on a thread pool in no particular order, and its buffers must not alias
+            tmp = torch.empty_like(shard)
+            dist.reduce_scatter_tensor(tmp, main.clone(), op=dist.ReduceOp.SUM, group=self.group)
+            handles.append(dist.all_gather_into_tensor(main, tmp, group=self.group, async_op=True))
+            handles.append(_Keep(tmp))
+        if tail.numel():
+            handles.append(dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._n_rs += 1
+        return handles
+
+    _n_rs = 0
+
     def _on_grad(self, p):
         g = p.grad
         if g is None:
@@ -159,7 +200,7 @@ class GradSync:
         if self._is_small(g):
             self._small[id(p)] = g
         else:
-            self._pending[id(p)] = (g, dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending[id(p)] = (g, self._reduce_large(g))
 
     def _buckets(self, grads):
         """Greedy fill in the given order: lists of gradients whose fp32 sizes sum to <= bucket_bytes."""
@@ -185,22 +226,27 @@ class GradSync:
         rest = [p.grad for p in params if id(p.grad) not in done]
         large = sorted((g for g in rest if not self._is_small(g)), key=lambda g: -g.numel())
         small = [g for g in rest if self._is_small(g)]
-        handles = [h for _, h in started]
+        handles = [h for _, hs in started for h in hs]
         for g in large:
-            handles.append(dist.all_reduce(_flat(g), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            handles += self._reduce_large(g)
         inv = 1.0 / ws
         flats = []
         for bucket in self._buckets(small):
             flat = torch.cat([_flat(g).reshape(-1).float() for g in bucket])
             flats.append((flat, bucket, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
-        self.stats = dict(large=len(started) + len(large), buckets=len(flats), small=len(small))
+        self.stats = dict(large=len(started) + len(large), buckets=len(flats), small=len(small), rs_ag=self._n_rs)
+        self._n_rs = 0
+        mark = self._mark() if self.timing else None
         for h in handles:
             h.wait()
+        for _, _, h in flats:
+            h.wait()
+        if mark is not None:
+            self._waits.append((mark, self._mark()))
         big = [g for g, _ in started] + large
         if big and not self.prescaled:
             torch._foreach_mul_(big, inv)
         for flat, bucket, h in flats:
-            h.wait()
             if not self.prescaled:
                 flat.mul_(inv)
             off = 0
@@ -208,6 +254,37 @@ class GradSync:
                 n = g.numel()
                 _flat(g).reshape(-1).copy_(flat[off:off + n])
                 off += n
+
+    def _mark(self):
+        if dist.get_backend(self.group) == "nccl":   # wait() only makes the compute stream wait: the stall is device time between two events
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def wait_ms(self, reset=True):
+        """Per call since the last reset: milliseconds the compute stream (RCCL) / the host (gloo) spent waiting for the exchange."""
+        out = []
+        for a, b in self._waits:
+            if isinstance(a, float):
+                out.append((b - a) * 1e3)
+            else:
+                b.synchronize()
+                out.append(a.elapsed_time(b))
+        if reset:
+            self._waits = []
+        return out
+
+
+class _Keep:
+    """A "work handle" that only keeps a staging buffer alive until the waits are over."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def wait(self):
+        return True
 
 
 # ---- small exchanges of the sharded non-training paths (slab mutex watershed) ---------------------------------------------------

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out, overlap=False):
     sync(list(net.parameters()))
     assert not sync._pending and not sync._small
     # all four tensors are far below 1 MB: they travel in ONE flat bucket, no per-tensor collective
-    assert sync.stats == dict(large=0, buckets=1, small=4), sync.stats
+    assert sync.stats == dict(large=0, buckets=1, small=4, rs_ag=0), sync.stats
     big = parallel.GradSync(small_bytes=64, bucket_bytes=256)   # thresholds scaled down: conv weights "large", biases bucketed
     for q in net.parameters():
         q.grad = torch.full_like(q, float(rank + 1))
@@ -200,3 +200,60 @@ def test_launch_ranks_supervises_its_children():
     assert launch_ranks([sys.executable, "-c", "import os; assert os.environ['WORLD_SIZE']=='2' and os.environ['MASTER_ADDR']=='127.0.0.1'"], 2) == 0
     rc = launch_ranks([sys.executable, "-c", "import os,signal,time; (os.kill(os.getpid(), signal.SIGKILL) if os.environ['RANK']=='0' else time.sleep(60))"], 2)
     assert rc == 128 + 9
+
+
+def _rsag_worker(rank, world, port, out, hooks):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from raygun_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(11 + rank)
+    # a conv weight in channels-last memory whose element count (7 * 5 * 27 = 945) is no multiple of the world size (tail path), a
+    # contiguous one that is, and a small one that must stay in the flat bucket
+    shapes = [((7, 5, 3, 3, 3), True), ((6, 4, 3, 3, 3), False), ((5,), False)]
+    def params():
+        ps = []
+        for shp, cl in shapes:
+            p = torch.nn.Parameter(torch.zeros(shp))
+            if cl:
+                p.data = p.data.contiguous(memory_format=torch.channels_last_3d)
+            ps.append(p)
+        return ps
+    grads = [torch.randn(shp, generator=g) for shp, _ in shapes]
+    res = {}
+    for algo in ("allreduce", "rs_ag"):
+        ps = params()
+        sync = parallel.GradSync(algo=algo, rs_min_bytes=1024, small_bytes=256, timing=True)
+        if hooks:
+            sync.attach(ps)
+            (sum((p * gr).sum() for p, gr in zip(ps, grads))).backward()      # d/dp = gr: the hooks start the exchanges
+        else:
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone().contiguous(memory_format=torch.channels_last_3d) if p.dim() == 5 and not p.is_contiguous() else gr.clone()
+        sync(ps)
+        assert sync.stats["rs_ag"] == (2 if algo == "rs_ag" else 0) and sync.stats["large"] == 2 and sync.stats["small"] == 1, (algo, sync.stats)
+        w = sync.wait_ms()
+        assert len(w) == 1 and w[0] >= 0.0 and sync.wait_ms() == []
+        res[algo] = [p.grad.clone() for p in ps]
+    out.put((rank, [float((a - b).abs().max()) for a, b in zip(res["allreduce"], res["rs_ag"])], [t.tolist() for t in res["rs_ag"][2:]],
+             [float(t.sum()) for t in res["rs_ag"]]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("hooks", [False, True])
+def test_reduce_scatter_all_gather_path_equals_all_reduce(hooks):
+    """GradSync(algo="rs_ag"): gradients >= rs_min_bytes travel as reduce-scatter + all-gather (+ an all-reduce of the < world-size tail) —
+    same averages as the all-reduce path on every rank, from the call and from the backward hooks (world size 3: 945 elements leave a tail)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rsag_worker, args=(r, world, port, q, hooks)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, errs, small, sums in res:
+        assert max(errs) <= 1e-6, (rank, errs)
+    assert all(r[2] == res[0][2] and r[3] == res[0][3] for r in res)      # rank-identical results
