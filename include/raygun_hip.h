@@ -56,7 +56,8 @@ const char* rg_last_error_string(void);
 const char* rg_last_kernel_name(void);
 /* Diagnostic switches (0 = production default): "RG_FM" (forced igemm4 tile height 1..4), "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3",
  * "RG_NO_WLINES", "RG_NO_KWP" (kernel families switched off: the launch falls through to the next candidate), "RG_GEMM5" (the LDS-DMA
- * GEMM of gemm5.hip: -1 off, 1 wherever its 144-column tiling allows, 0 the heuristic), "RG_DEBUG_BOUNDS"
+ * GEMM of gemm5.hip: -1 off, 1 wherever its 144-column tiling allows, 0 the heuristic), "RG_NO_WGEMM" (1: the wide weight gradients stay on wgrad_kwp instead of
+ * the transposed-operand GEMM form), "RG_DEBUG_BOUNDS"
  * (every entry point re-derives the byte extent its kernels may touch from the descriptors and fails with RG_ERR_BAD_SHAPE instead
  * of launching when a workspace / packed operand / view is smaller).  The environment variables of the same names are read ONCE,
  * when the library is loaded; no launch path reads the environment.  Process-wide. */
@@ -322,6 +323,37 @@ int64_t rg_mws_graph_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uint32_t* eu, const uint32_t* ev, const uint8_t* attractive,
                  int64_t n_edges, int64_t n_nodes, int32_t* rep, void* workspace, size_t ws_bytes, rg_stream s);
 int rg_mws_relabel(int64_t* labels, const int64_t* lut, int64_t n, rg_stream s);
+
+/* ---- the DEFAULT raygun-segment route: seeded watershed on the boundary-distance transform + waterz-style agglomeration
+ * (reference: src/raygun/segment.py:15-136 `watershed_from_boundary_distance` / `watershed_from_affinities` / `get_segmentation`, dispatched from
+ * `segment` :233-296; replaces scipy.ndimage.{distance_transform_edt, maximum_filter, label}, skimage.segmentation.watershed and waterz.agglomerate
+ * on that path).  All volumes are dense C-order (Z, Y, X) device arrays, `shape` = host int32[3], < 2^31 voxels, extents < 16384.
+ *   rg_ws_mask      segment.py:93    mask = mean over the n_channels float32 affinity channels > thresh, in numpy's float32 arithmetic
+ *   rg_ws_edt       segment.py:94    EXACT squared Euclidean distance (int32) to the nearest mask == 0 voxel inside the volume
+ *   rg_ws_maxima    segment.py:25-26 maxima[v] = (maximum filter of `size` with scipy's window / reflected borders) == d2[v]
+ *   rg_ws_label     segment.py:27    6-connected components numbered 1.. by their first voxel in raster order (scipy.ndimage.label); *n_out (device)
+ *   rg_ws_flood     segment.py:36-38 seeded watershed of (max distance - distance) within the mask: the build-defined minimum-spanning-forest order
+ *                                    (see csrc/watershed.hip; parity unpinned against skimage); synchronises; *rounds_out (host, optional)
+ *   rg_ws_rag_*     waterz region graph: one 64-bit record (u << 36 | v << 8 | bin) per (voxel, axis) whose ends carry different non-zero fragment ids
+ *                   u < v < 2^28, bin = (int)(affinity * 255) of affs[axis][voxel]; count first, then emit into `keys` (*cursor_dev ends as the count)
+ *   rg_ws_agglomerate (HOST arrays, no device work) waterz's iterative region merging with OneMinus<HistogramQuantileAffinity<.., 75, .., 256, false>>
+ *                   over sorted unique records + multiplicities; lut_out[t * (n_fragments + 1) + id] = surviving fragment id at thresholds[t] (ascending)
+ *   rg_ws_relabel   out[v] = lut[fragments[v]] */
+int rg_ws_mask(const float* affs, int32_t n_channels, int64_t n_voxels, float thresh, uint8_t* mask, rg_stream s);
+int64_t rg_ws_edt_workspace_bytes(const int32_t* shape);
+int rg_ws_edt(const uint8_t* mask, const int32_t* shape, int32_t* d2, void* workspace, size_t ws_bytes, rg_stream s);
+int64_t rg_ws_maxima_workspace_bytes(const int32_t* shape);
+int rg_ws_maxima(const int32_t* d2, const int32_t* shape, int32_t size, uint8_t* maxima, void* workspace, size_t ws_bytes, rg_stream s);
+int64_t rg_ws_label_workspace_bytes(const int32_t* shape);
+int rg_ws_label(const uint8_t* fg, const int32_t* shape, int32_t* labels, int32_t* n_out, void* workspace, size_t ws_bytes, rg_stream s);
+int64_t rg_ws_flood_workspace_bytes(const int32_t* shape);
+int rg_ws_flood(const int32_t* d2, const int32_t* markers, const uint8_t* mask, const int32_t* shape, int32_t* out, int32_t* rounds_out,
+                void* workspace, size_t ws_bytes, rg_stream s);
+int rg_ws_rag_count(const int32_t* fragments, const int32_t* shape, uint64_t* count_dev, rg_stream s);
+int rg_ws_rag_emit(const int32_t* fragments, const float* affs, const int32_t* shape, uint64_t* keys, uint64_t capacity, uint64_t* cursor_dev, rg_stream s);
+int rg_ws_agglomerate(const uint64_t* keys, const int64_t* counts, int64_t n_records, int64_t n_fragments, const float* thresholds, int32_t n_thresholds,
+                      int64_t* lut_out);
+int rg_ws_relabel(const int32_t* fragments, const int64_t* lut, int64_t* out, int64_t n_voxels, rg_stream s);
 
 /* ---- host-side codec for the chunk reader (no device work): one LZ4 block (the stream format inside zarr's default Blosc
  * compressor) -> dst; returns the number of bytes written or -1 on malformed input / a too small buffer. */

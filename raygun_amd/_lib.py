@@ -122,11 +122,24 @@ _SIGS = {
     "rg_mws_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_size_t, C.c_void_p]),
     "rg_mws_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rg_ws_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "rg_ws_edt_workspace_bytes": (C.c_int64, [_I3]),
+    "rg_ws_edt": (C.c_int, [C.c_void_p, _I3, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_ws_maxima_workspace_bytes": (C.c_int64, [_I3]),
+    "rg_ws_maxima": (C.c_int, [C.c_void_p, _I3, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_ws_label_workspace_bytes": (C.c_int64, [_I3]),
+    "rg_ws_label": (C.c_int, [C.c_void_p, _I3, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_ws_flood_workspace_bytes": (C.c_int64, [_I3]),
+    "rg_ws_flood": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _I3, C.c_void_p, _P(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rg_ws_rag_count": (C.c_int, [C.c_void_p, _I3, C.c_void_p, C.c_void_p]),
+    "rg_ws_rag_emit": (C.c_int, [C.c_void_p, C.c_void_p, _I3, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rg_ws_agglomerate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rg_ws_relabel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 DECLARED = sorted(_SIGS)
 _F16_ABSENT = {"rg_add_affinities", "rg_balance_labels_workspace_bytes", "rg_balance_labels", "rg_lsd_targets", "rg_mws_workspace_bytes", "rg_mws_prepare", "rg_mws_prepare_u8", "rg_mws_segment", "rg_mws_segment_u8", "rg_mws_cross_edges_u8", "rg_mws_stats", "rg_mws_cross_edges", "rg_mws_slab_mutexes",
-               "rg_mws_graph_workspace_bytes", "rg_mws_graph", "rg_mws_relabel"}  # no 16-bit data on the mutex-watershed path
+               "rg_mws_graph_workspace_bytes", "rg_mws_graph", "rg_mws_relabel"} | {n for n in _SIGS if n.startswith("rg_ws_")}  # no 16-bit data on the watershed paths
 _libs = {}
 import threading
 _tls = threading.local()

@@ -13,7 +13,7 @@ LIB_F16 = os.path.join(LIBDIR, "libraygun_hip_f16.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=off"]
 VARIANTS = (("", [], LIB), ("_f16", ["-DRG_STORE_F16=1"], LIB_F16))
-F16_SKIP = {"mws.hip", "targets.hip"}  # no 16-bit data on that path: the mutex watershed lives in the bf16 library only
+F16_SKIP = {"mws.hip", "targets.hip", "watershed.hip"}  # no 16-bit data on that path: the mutex watershed lives in the bf16 library only
 
 
 def sources():

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   const long m0 = (long)tile_m * G5_BM;
   const int n0 = tile_n * G5_BN;
   const bf16_t* const xbase = a.x + batch * a.xbatch;
-  const bf16_t* const wbase = a.w + batch * a.wbatch;
+  const bf16_t* const wbase = a.nbatch1 ? a.w + (batch % a.nbatch1) * a.wbatch + (batch / a.nbatch1) * a.wbatch2 : a.w + batch * a.wbatch;
   bf16_t* const ybase = a.y + batch * a.ybatch;
   const g5_i32x4 ra = g5_rsrc(xbase, a.xbytes), rw = g5_rsrc(wbase, a.wbytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)g5_lds;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int r = i * 64 + drow, n = n0 + r;
-    vb[i] = (r < G5_BN && n < a.wrows) ? (unsigned)(((long)n * ntaps * a.cink + dpiece * 8) * 2) : G5_OOB;
+    vb[i] = (r < G5_BN && n < a.wrows) ? (unsigned)(((long)n * (a.wld ? a.wld : (long)ntaps * a.cink) + dpiece * 8) * 2) : G5_OOB;
   }
   const unsigned dma_lds = lds0 + wave * 1024;                   // + stage * G5_STAGE + (A: i * 8192 | B: 32768 + i * 8192)
 
@@ -211,6 +211,25 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   if (!wn) __builtin_amdgcn_s_barrier();     // matches the trailing group's extra barrier
 
   // ---- epilogue: lane holds columns c .. c+3 of row (lane & 15) of every fragment
+  if (a.raw) {          // raw fp32 tile straight into the caller's matrix (the weight gradient: row = output channel, column = input channel of one tap)
+    float* const obase = a.raw + batch * a.raw_batch;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wm * 64 + i * 16 + fr;
+      if (m >= a.M) continue;
+      float* prow = obase + m * a.raw_ld;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
+        if (c + 3 < a.cout) *(f32x4*)(prow + c) = acc[i][j];
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (c + r < a.cout) prow[c + r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   if (a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the 16-bit store happen in the combine kernel
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -320,5 +339,124 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
     else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
   }
   if (a.ksplit > 1) rg_launch_igemm4_combine(a, st);
+  return RG_OK;
+}
+
+// ---- the weight gradient as a batched GEMM --------------------------------------------------------------------------------------
+// dW[a][tap][b] = sum_rows G[row][a] X[row @ tap][b] reduces over voxels — the SLOW dimension of both channels-last operands, which is why
+// wgrad_kw* (wgrad.hip) read every fragment with the transposing ds_read_b64_tr_b16: 24 of them per 27 MFMAs, and the kernel sits at ~850 TFLOP/s
+// (34 % of peak, MFMA pipe 39 % busy) whichever way its tiles reach LDS (round 3: producer waves and LDS-DMA measured level).  For the layers
+// whose operands are SMALL next to their FLOPs (config U's 2592 -> 2592 at 17^3: 2 x 36 MB for 1.8 TFLOP) it pays to transpose the operands
+// once, in HBM, and run the reduction as what it then is — 27 plain GEMMs with K-contiguous rows on igemm5 (1.2 PFLOP/s on this shape class):
+//   GT[a][od][P]                  = G[od][oh][ow][a]                p = oh * OW + ow, plane padded to P = 64-element lines with ZEROS
+//   XT[(kh, kw)][b][d][P]         = X[d][oh + kh][ow + kw][b]       one copy per in-plane tap: the kd taps are a K offset of kd * P
+//   dW[a][(kd, kh, kw)][b]        = sum_k GT[a][k] * XT[(kh, kw)][b][kd * P + k]        k = od * P + p
+// (wgrad_transpose_kernel below writes both; igemm5 runs batch (b1, b2) = ((kh, kw), kd) with B offset b1 * copy + b2 * P, B rows ID * P apart, raw fp32
+// output at column offset tap * B: the channels-last gradient itself, no split-K, no reduction pass).
+struct WgradTrArgs { const bf16_t* src; bf16_t* dst; int C, lanes, D, OH, OW, P, KH, KW; long ssd, ssh, ssw; long copy_stride, row_stride; };
+__global__ __launch_bounds__(256) void wgrad_transpose_kernel(WgradTrArgs t) {
+  // block = (64 positions of one plane d) x (64 channels) of copy j: read channel-fastest 16-byte pieces, write position-fastest 16-byte pieces
+  __shared__ bf16_t tile[64][72];
+  const int j = blockIdx.z % (t.KH * t.KW), d = blockIdx.z / (t.KH * t.KW);
+  const int kh = j / t.KW, kw = j % t.KW;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = tid; q < 64 * 8; q += 256) {          // 64 positions x 8 pieces of 8 channels
+    const int pp = q >> 3, pc = (q & 7) * 8, pos = p0 + pp, c = c0 + pc;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (pos < t.OH * t.OW && c < t.lanes) {
+      const int oh = pos / t.OW, ow = pos - oh * t.OW;
+      v = *(const u32x4_t*)(t.src + (long)d * t.ssd + (long)(oh + kh) * t.ssh + (long)(ow + kw) * t.ssw + c);
+    }
+    *(u32x4_t*)&tile[pp][pc] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = tid; q < 64 * 8; q += 256) {          // 64 channels x 8 pieces of 8 positions
+    const int cc = q >> 3, pq = (q & 7) * 8, c = c0 + cc;
+    if (c >= t.C) continue;
+    bf16_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = tile[pq + k][cc];
+    *(u32x4_t*)(t.dst + (long)j * t.copy_stride + (long)c * t.row_stride + (long)d * t.P + p0 + pq) = *(const u32x4_t*)o;
+  }
+}
+
+struct WgradGemmPlan { int ok; int P, OD, planes, K, fn; size_t gt_el, xt_el; };
+static WgradGemmPlan wgrad_gemm_plan(const CL5& G, const CL5& X, const rg_conv_params* p) {
+  WgradGemmPlan pl; memset(&pl, 0, sizeof(pl));
+  if (rg_opt(RG_OPT_GEMM5) < 0 || G.N != 1) return pl;
+  for (int d = 0; d < 3; ++d)
+    if (p->rstride[d] != 1 || p->tstep[d] != 1 || p->tbase[d] < 0) return pl;
+  const int I[3] = {X.D, X.H, X.W};
+  for (int d = 0; d < 3; ++d) if (p->tbase[d] + p->T[d] - 1 + p->R[d] - 1 >= I[d]) return pl;     // valid region only: no zero padding
+  const int nf = round_up(X.C, 16) / 16;
+  const int fn = nf % 9 == 0 ? 9 : (nf % 8 == 0 ? 8 : 0);
+  if (!fn || (X.C & 7) || G.C < 1024 || X.C < 1024) return pl;       // the operands must be small next to the FLOPs: wide layers only
+  const int P = round_up(p->R[1] * p->R[2], 64), K = p->R[0] * P;
+  const long tiles_m = (G.C + G5_BM - 1) / G5_BM, tiles_n = (round_up(X.C, 16) + 2 * fn * 16 - 1) / (2 * fn * 16);
+  const double fill = (double)G.C / (tiles_m * G5_BM) * (double)X.C / (tiles_n * 2 * fn * 16) * (double)(p->R[1] * p->R[2]) / P;
+  const long wgs = tiles_m * tiles_n * p->T[0] * p->T[1] * p->T[2];
+  const double rounds = (double)wgs / 256.0, round_fill = rounds / (double)(long)(rounds + 0.999999);   // ONE workgroup per CU
+  if (fill < 0.70 || K < 32 * 64 || wgs < 256 || round_fill < 0.70) return pl;
+  const int planes = p->R[0] + p->T[0] - 1;
+  pl.P = P; pl.OD = p->R[0]; pl.planes = planes; pl.K = K; pl.fn = fn;
+  pl.gt_el = (size_t)G.C * K;
+  pl.xt_el = (size_t)p->T[1] * p->T[2] * round_up(X.C, 16) * planes * P;      // (rows up to the 16-row fragment: igemm5 reads them, their columns are never stored)
+  if (pl.gt_el * 2 >= (1ul << 30) || pl.xt_el * 2 >= (1ul << 31)) return pl;   // 32-bit buffer offsets
+  pl.ok = 1;
+  return pl;
+}
+// workspace bytes of the GEMM form, 0 when the problem does not take it
+size_t rg_wgrad_gemm_bytes(const CL5& G, const CL5& X, const rg_conv_params* p) {
+  const WgradGemmPlan pl = wgrad_gemm_plan(G, X, p);
+  return pl.ok ? (pl.gt_el + pl.xt_el) * 2 + 256 : 0;
+}
+int rg_launch_wgrad_gemm(const CL5& G, const CL5& X, const rg_conv_params* p, float* dw, void* workspace, size_t ws_bytes, hipStream_t st) {
+  const WgradGemmPlan pl = wgrad_gemm_plan(G, X, p);
+  if (!pl.ok) return RG_ERR_UNSUPPORTED;
+  if (ws_bytes < (pl.gt_el + pl.xt_el) * 2 + 256) RG_FAIL(RG_ERR_WORKSPACE, "wgrad (GEMM form): workspace %zu bytes too small", ws_bytes);
+  bf16_t* gt = (bf16_t*)(((uintptr_t)workspace + 127) & ~(uintptr_t)127);
+  bf16_t* xt = gt + pl.gt_el;
+  const int KH = p->T[1], KW = p->T[2], KD = p->T[0];
+  WgradTrArgs tg; tg.src = G.p; tg.dst = gt; tg.C = G.C; tg.lanes = G.lanes; tg.D = pl.OD; tg.OH = p->R[1]; tg.OW = p->R[2]; tg.P = pl.P; tg.KH = 1; tg.KW = 1;
+  tg.ssd = G.sd; tg.ssh = G.sh; tg.ssw = G.sw; tg.copy_stride = 0; tg.row_stride = pl.K;
+  rg_prof_mark(st);      // (the two transposing passes are part of this path's cost: inside the bracket)
+  hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(pl.P / 64, (G.C + 63) / 64, pl.OD), dim3(256), 0, st, tg);
+  WgradTrArgs tx; tx.src = X.p + (long)p->tbase[0] * X.sd + (long)p->tbase[1] * X.sh + (long)p->tbase[2] * X.sw;
+  tx.dst = xt; tx.C = X.C; tx.lanes = X.lanes; tx.D = pl.planes; tx.OH = p->R[1]; tx.OW = p->R[2]; tx.P = pl.P; tx.KH = KH; tx.KW = KW;
+  tx.ssd = X.sd; tx.ssh = X.sh; tx.ssw = X.sw; tx.row_stride = (long)pl.planes * pl.P; tx.copy_stride = (long)round_up(X.C, 16) * tx.row_stride;
+  hipLaunchKernelGGL(wgrad_transpose_kernel, dim3(pl.P / 64, (X.C + 63) / 64, pl.planes * KH * KW), dim3(256), 0, st, tx);
+  Igemm4Args a; memset(&a, 0, sizeof(a));
+  a.x = gt; a.w = xt; a.bias = nullptr; a.y = nullptr;
+  a.N = 1; a.ID = 1; a.IH = 1; a.IW = G.C;
+  a.RD = 1; a.RH = 1; a.RW = G.C; a.TD = a.TH = a.TW = 1;
+  for (int d = 0; d < 3; ++d) { a.rs[d] = 1; a.tb[d] = 0; a.ts[d] = 1; a.os[d] = 1; a.oo[d] = 0; }
+  a.xsn = a.xsd = a.xsh = (long)G.C * pl.K; a.xsw = pl.K;
+  a.cink = pl.K; a.cin_lanes = pl.K; a.cout = X.C; a.cout_lanes = round_up(X.C, 8); a.wrows = round_up(X.C, 16);
+  a.act = RG_ACT_NONE; a.slope = 0.f;
+  a.M = G.C;
+  a.xbytes = (unsigned)(pl.gt_el * 2);
+  a.wbytes = (unsigned)(pl.xt_el * 2);
+  a.krow = 0; a.cp = 0; a.ksplit = 1; a.part = nullptr;
+  a.nbatch = KD * KH * KW; a.xbatch = 0; a.ybatch = 0;
+  a.nbatch1 = KH * KW; a.wbatch = tx.copy_stride; a.wbatch2 = pl.P;      // batch = kd * (KH * KW) + (kh * KW + kw) = the tap index
+  a.wld = tx.row_stride;
+  a.raw = dw; a.raw_ld = (long)KD * KH * KW * X.C; a.raw_batch = X.C;
+  a.d2s_c = 0;
+  const int bn = 2 * pl.fn * 16;
+  a.tiles_m = (int)((a.M + G5_BM - 1) / G5_BM);
+  a.tiles_n = (a.wrows + bn - 1) / bn;
+  static rg_device_latch attr;
+  rg_once_per_device(&attr, [] {
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+  });
+  rg_set_kernel_name("wgrad_gemm[igemm5_kernel<0,%d>]", pl.fn);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.nbatch));
+  if (pl.fn == 9) hipLaunchKernelGGL((igemm5_kernel<false, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  rg_prof_mark(st);
   return RG_OK;
 }

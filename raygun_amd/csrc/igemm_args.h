@@ -18,6 +18,10 @@ struct Igemm4Args {
   int krow, cp;             // FLAT: packed row length (elements, multiple of 64), 8-lane pieces per tap
   int ksplit; float* part;  // split-K (grids that leave most CUs idle): ksplit > 1 -> fp32 partial sums [split][row][cout_lanes] into `part`
   int nbatch; long xbatch, wbatch, ybatch;  // batched GEMM (rg_gemm_batched): element strides between the problems; no split-K
+  // igemm5 only — the GEMM form of the weight gradient (gemm5.hip rg_wgrad_gemm): B rows `wld` elements apart (0: ntaps * cink), a second batch level
+  // (batch = b2 * nbatch1 + b1: operand B of batch (b1, b2) starts wbatch * b1 + wbatch2 * b2 elements in), and raw fp32 output: element (m, n) of
+  // batch b goes to raw + b * raw_batch + m * raw_ld + n (no bias / activation / 16-bit store); raw = nullptr: off
+  long wld; int nbatch1; long wbatch2; float* raw; long raw_ld, raw_batch;
   int d2s_c;  // igemm5 only, 0 = off: the columns are 8 parity classes x d2s_c channels of a sub-pixel (stride-2 transposed) convolution — column
               // c goes to channel c % d2s_c of output voxel 2 * row + parity(c / d2s_c) (depth-to-space in the epilogue; os = 2, bias per channel)
 };

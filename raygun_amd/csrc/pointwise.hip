@@ -25,7 +25,7 @@ extern "C" int rg_version(void) { return 101; }
 #include <atomic>
 #include <mutex>
 #include <stdlib.h>
-static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5"};
+static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5", "RG_NO_WGEMM"};
 static std::atomic<int> g_opt[RG_OPT_COUNT];
 static const bool g_opt_init = [] {   // environment -> switches, once, when the library is loaded
   for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? ((i == RG_OPT_FM || i == RG_OPT_GEMM5) ? atoi(e) : (e[0] && e[0] != '0')) : 0); }

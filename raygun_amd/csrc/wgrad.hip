@@ -1123,6 +1123,8 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   *rows_per_split = rps;
 }
 
+size_t rg_wgrad_gemm_bytes(const CL5& G, const CL5& X, const rg_conv_params* p);                                                   // gemm5.hip
+int rg_launch_wgrad_gemm(const CL5& G, const CL5& X, const rg_conv_params* p, float* dw, void* workspace, size_t ws_bytes, hipStream_t st);
 static int wgrad_check(const rg_tensor* g, const rg_tensor* x, const rg_conv_params* p, CL5* G, CL5* X) {
   int rc;
   if ((rc = rg_as_cl5(g, G, "wgrad.g")) || (rc = rg_as_cl5(x, X, "wgrad.x"))) return rc;
@@ -1139,7 +1141,9 @@ extern "C" int64_t rg_conv3d_wgrad_workspace_bytes(const rg_tensor* g, const rg_
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   if (nsplit_out) *nsplit_out = ns;
   const int64_t total = (int64_t)G.C * X.C * p->T[0] * p->T[1] * p->T[2];
-  return (ns + (ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;  // (an upper bound of what rg_conv3d_wgrad2 uses)
+  const int64_t split_bytes = (ns + (ns > 8 ? (ns + WF_FOLD - 1) / WF_FOLD : 0)) * total * 4;  // (an upper bound of what rg_conv3d_wgrad2 uses)
+  const int64_t gemm_bytes = (int64_t)rg_wgrad_gemm_bytes(G, X, p);   // the GEMM form (gemm5.hip): two transposed operand copies instead of partial sums
+  return gemm_bytes > split_bytes ? gemm_bytes : split_bytes;
 }
 
 template <int FA, int FB, int WA, int WB>
@@ -1206,6 +1210,10 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
   CL5 G, X;
   int rc;
   if ((rc = wgrad_check(g, x, p, &G, &X))) return rc;
+  if (dw_cl && !accumulate && dw && workspace && !rg_opt(RG_OPT_NO_WGEMM)) {   // wide layers: transposed operands + 27 plain GEMMs on igemm5 (gemm5.hip)
+    const size_t gb = rg_wgrad_gemm_bytes(G, X, p);
+    if (gb && ws_bytes >= gb) { rc = rg_launch_wgrad_gemm(G, X, p, dw, workspace, ws_bytes, (hipStream_t)s); if (rc) return rc; RG_CHECK_LAUNCH(); return RG_OK; }
+  }
   int fa, fb, ns; long rps;
   wgrad_plan(G, X, p, &fa, &fb, &ns, &rps);
   const int ntaps = p->T[0] * p->T[1] * p->T[2];

@@ -2,9 +2,9 @@
 (reference: src/raygun/segment.py:139-230 `mutex_segment`, :233-248 `segment`).
 
 `compute_mws_segmentation` has affogato's call signature as used at segment.py:197-199 and runs
-rg_mws_segment (edge keys -> device radix sort -> wavefront-level union-find with mutex lists).  The seeded
-watershed + waterz agglomeration branch of segment.py (:46-136) is a different algorithm and out of scope
-(SURVEY.md §2 #13b): `segment(config)` with mutex=False raises.
+rg_mws_segment (edge keys -> device radix sort -> wavefront-level union-find with mutex lists).  The DEFAULT route of
+segment.py (:46-136: seeded watershed on the boundary-distance transform + waterz agglomeration) lives in
+raygun_amd/watershed.py; `segment(config)` dispatches to it unless the config says "mutex": true.
 
 Volumes are taken from the config's zarr container (the `zarr` package when importable, else raygun_amd.zarrio), or
 passed in memory (`affs=` keyword / config["affs"] as an ndarray or a .npy path) — the reference reads the whole array
@@ -447,15 +447,58 @@ def mutex_segment(config_path, affs=None):
 
 
 def segment(config_path=None, affs=None):
-    """segment.py:233-296 — only the mutex branch is built.  `python -m raygun_amd.segment seg.json` = raygun-segment."""
+    """segment.py:233-296 — `python -m raygun_amd.segment seg.json` = raygun-segment.  "mutex": true -> mutex_segment; otherwise the reference's default
+    route: fragments by the seeded watershed on the boundary-distance transform, one waterz-style agglomeration per threshold (raygun_amd.watershed), the
+    segmentations written next to the affinities as `pred_seg_<threshold>` with their offset / resolution and listed in the neuroglancer view script.
+    `affs` (keyword, or config["affs"] as an array / .npy path) segments an in-memory (3, Z, Y, X) array instead of the container's; returns the list of
+    segmentations (uint64 arrays)."""
     if config_path is None:
         import sys
         config_path = sys.argv[1]
-    cfg = read_config(config_path)
-    if cfg.get("mutex", False):
+    seg_config = {"aff_ds": "pred_affs", "thresholds": [t for t in np.arange(0.1, 0.9, 0.1)], "mutex": False, "max_affinity_value": 1.0, "labels_mask": None}
+    seg_config.update(read_config(config_path))
+    if seg_config["mutex"]:
         return mutex_segment(config_path, affs=affs)
-    raise NotImplementedError("raygun_amd.segment: the seeded-watershed + waterz branch (segment.py:250-296) is out of "
-                              "scope; set \"mutex\": true")
+    from . import watershed
+    thresholds = seg_config["thresholds"]
+    if affs is None:
+        affs = seg_config.get("affs")
+    if isinstance(affs, str):
+        affs = np.load(affs)
+    if affs is not None:   # in memory: nothing to skip, nothing to write unless a container is named as well
+        segs = watershed.get_segmentation(np.asarray(affs, dtype=np.float32) if not torch.is_tensor(affs) else affs, thresholds=list(thresholds),
+                                          labels_mask=seg_config["labels_mask"], max_affinity_value=seg_config["max_affinity_value"])
+        if "file" not in seg_config or ("save" in seg_config and not seg_config["save"]):
+            return segs
+    file, aff_ds = seg_config["file"], seg_config["aff_ds"]
+    done = True
+    for thresh in thresholds:
+        done = done and os.path.exists(os.path.join(file, "pred_seg_%.2f" % thresh))
+    try:
+        import zarr
+    except ImportError:
+        from . import zarrio as zarr  # zarr v2 directory stores with stdlib codecs (see zarrio.py)
+    f = zarr.open(file, "a")
+    segs = None if affs is None else segs
+    if not done:
+        if segs is None:
+            prediction = np.asarray(f[aff_ds][:]).astype(np.float32)
+            segs = watershed.get_segmentation(prediction, thresholds=list(thresholds), labels_mask=seg_config["labels_mask"],
+                                              max_affinity_value=seg_config["max_affinity_value"])
+        where = os.path.dirname(config_path) if isinstance(config_path, str) else file      # (a dict config has no directory: beside the container)
+        view_script = os.path.join(where, f"view_{os.path.basename(file).rstrip('.n5').rstrip('.zarr')}.ng")
+        for thresh, seg in zip(thresholds, segs):
+            dest_dataset = f'pred_seg_{"{:.2f}".format(thresh)}'
+            f[dest_dataset] = seg
+            f[dest_dataset].attrs["offset"] = f[aff_ds].attrs["offset"]
+            f[dest_dataset].attrs["resolution"] = f[aff_ds].attrs["resolution"]
+            if not os.path.exists(view_script):
+                with open(view_script, "w") as v:
+                    v.write(f"neuroglancer -f {file} -d {dest_dataset} ")
+            else:
+                with open(view_script, "a") as v:
+                    v.write(f"{dest_dataset} ")
+    return segs
 
 
 if __name__ == "__main__":

@@ -990,3 +990,34 @@ def test_igemm5_split_k_small_grid():
     assert "igemm5" in name and "splitK" in name, name
     (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
     assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL, (relerr(y, yr), relerr(gx, gxr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,k", [
+    (1152, 1280, (10, 18, 18), 3),      # plane 16 x 16 = 256 (no padding), 8 output planes, 27 batches, full tiles
+    (1152, 1100, (34, 17, 17), 3),      # ragged: 1100 rows (last A tile 76 rows), plane 15 x 15 = 225 -> 256 zero-padded, 32 output planes
+    (1024, 2048, (17, 17, 17), 2),      # 2^3 taps (the sub-pixel layers), FN = 8 column tiles, plane 256: 256 workgroups = one round
+])
+def test_wgrad_gemm_form_wide_layers(cin, cout, sp, k):
+    """The GEMM form of the weight gradient (gemm5.hip rg_launch_wgrad_gemm: both operands transposed once in HBM — zero-padded planes, one X copy per
+    in-plane tap — then one raw-fp32-output igemm5 launch with a batch per tap) against torch fp32 on the CPU and against the producer-wave kernel
+    (RG_NO_WGEMM = 1) on the same operands."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    x0 = rnd((1, cin) + sp, 197); w0 = rnd((cout, cin, k, k, k), 198, -0.05, 0.05)
+    wr = w0.clone().requires_grad_()
+    yr = F.conv3d(x0, wr, None)
+    go = rnd(tuple(yr.shape), 199)
+    (gwr,) = torch.autograd.grad(yr, wr, go)
+    outs = {}
+    for off in (0, 1):
+        with ops.option("RG_NO_WGEMM", off):
+            wd = w0.clone().to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_()     # hipnn.Conv3d keeps its masters this way
+            y = ops.conv3d(x0.to(dev), wd, None, 1, 0, "none")
+            ops.profile_start()
+            (gw,) = torch.autograd.grad(y, wd, go.to(dev).to(y.dtype))
+            names = list(ops.profile_stop())
+            assert any("wgrad_gemm" in nm for nm in names) == (off == 0), names
+            assert relerr(gw, gwr) <= TOL, (off, relerr(gw, gwr))
+            outs[off] = gw.float().cpu()
+    assert relerr(outs[0], outs[1]) <= 2 ** -9
