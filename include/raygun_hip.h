@@ -358,6 +358,10 @@ int rg_ws_relabel(const int32_t* fragments, const int64_t* lut, int64_t* out, in
 /* ---- host-side codec for the chunk reader (no device work): one LZ4 block (the stream format inside zarr's default Blosc
  * compressor) -> dst; returns the number of bytes written or -1 on malformed input / a too small buffer. */
 int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+/* the writer's side (Blosc / lz4 frames for predict's zarr destinations, src/raygun/predict.py:111-125 -> daisy.prepare_ds's default compressor): one
+ * LZ4 block (greedy matcher, 64 KiB window); returns the compressed size or -1 when dst_cap < what the input needs (rg_lz4_compress_bound(n) always fits). */
+int64_t rg_lz4_compress_bound(int64_t n);
+int64_t rg_lz4_compress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
 
 /* ---- train-time target generation of the MTLSD system (reference: src/raygun/io/MTLSDDataPipe.py:99-131; gunpowder's AddAffinities /
  * BalanceLabels and lsd's AddLocalShapeDescriptor restated — parity unpinned against those packages, oracle/targets.py).  Dense device

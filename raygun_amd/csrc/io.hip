@@ -34,3 +34,52 @@ extern "C" int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, 
   }
   return op;
 }
+
+// LZ4 block COMPRESSION (greedy, one 64 Ki-entry hash table of 4-byte sequences, 64 KiB window) — what the chunk writer needs to lay down Blosc / lz4
+// frames (zarr's and daisy.prepare_ds's default compressor) at memory speed instead of python-zlib speed (predict's zarr destinations: 34 MB per block).
+// Follows the block format's end-of-block rules: the last match starts at least 12 bytes before the end, the last 5 bytes are literals.
+// Returns the compressed size, or -1 when dst_cap is too small (callers then store the block raw).  Any valid LZ4 decoder reads the output.
+static inline uint32_t lz4_read32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+extern "C" int64_t rg_lz4_compress_bound(int64_t n) { return n < 0 ? -1 : n + n / 255 + 16; }
+extern "C" int64_t rg_lz4_compress_block(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dst_cap) {
+  if (!src || !dst || n < 0 || dst_cap < 0 || n > 0x7E000000) return -1;
+  enum { HLOG = 16 };
+  static thread_local uint32_t table[1 << HLOG];             // position + 1 (0 = empty)
+  memset(table, 0, sizeof(table));
+  int64_t ip = 0, anchor = 0, op = 0;
+  auto emit = [&](int64_t lit, int64_t ml, int64_t off) -> bool {   // ml < 0: the closing literal run
+    const int64_t need = 1 + lit / 255 + 1 + lit + (ml >= 0 ? 2 + (ml - 4) / 255 + 1 : 0);
+    if (op + need > dst_cap) return false;
+    uint8_t* tok = dst + op++;
+    if (lit >= 15) { *tok = 0xF0; int64_t r = lit - 15; while (r >= 255) { dst[op++] = 255; r -= 255; } dst[op++] = (uint8_t)r; }
+    else *tok = (uint8_t)(lit << 4);
+    memcpy(dst + op, src + anchor, (size_t)lit); op += lit;
+    if (ml < 0) return true;
+    dst[op++] = (uint8_t)(off & 255); dst[op++] = (uint8_t)(off >> 8);
+    int64_t m = ml - 4;
+    if (m >= 15) { *tok |= 15; m -= 15; while (m >= 255) { dst[op++] = 255; m -= 255; } dst[op++] = (uint8_t)m; }
+    else *tok |= (uint8_t)m;
+    return true;
+  };
+  if (n >= 13) {
+    const int64_t mflimit = n - 12, matchlimit = n - 5;
+    unsigned misses = 0;
+    while (ip < mflimit) {
+      const uint32_t seq = lz4_read32(src + ip);
+      const uint32_t h = (seq * 2654435761u) >> (32 - HLOG);
+      const int64_t ref = (int64_t)table[h] - 1;
+      table[h] = (uint32_t)(ip + 1);
+      if (ref >= 0 && ip - ref <= 65535 && lz4_read32(src + ref) == seq) {
+        int64_t ml = 4;
+        while (ip + ml < matchlimit && src[ref + ml] == src[ip + ml]) ++ml;
+        if (!emit(ip - anchor, ml, ip - ref)) return -1;
+        ip += ml; anchor = ip; misses = 0;
+        if (ip - 2 > ref && ip - 2 < mflimit) table[(lz4_read32(src + ip - 2) * 2654435761u) >> (32 - HLOG)] = (uint32_t)(ip - 2 + 1);
+      } else {
+        ip += 1 + (misses++ >> 6);                            // incompressible stretches are skipped faster and faster
+      }
+    }
+  }
+  if (!emit(n - anchor, -1, 0)) return -1;
+  return op;
+}

@@ -284,11 +284,15 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
   const unsigned N = (unsigned)((long)Z * Y * X);
   const unsigned ne = *count;
   unsigned bar_target = 0, next = 0, nsurv = 0, pend = 0;   // pend: list operations of the previous round, applied at the head of this one
+  // Window size, adapted per round from what every thread sees alike (the survivor count): while at least 90 % of a round's entries retire the round is
+  // paid for by its two grid barriers and its chains of dependent loads, not by its entries — double the window (structured volumes: 70 rounds of
+  // 0.33 M entries become ~20 of up to 4 M); when less than half retire, entries are mostly blocked and every round re-examines them — halve it.
+  unsigned wt = wmul * T;
   uint4* win = win0; uint4* wout = win1;
   for (unsigned round = 1;; ++round) {
     // fresh edges this round: top the window up to ~2 entries per thread (the survivors already hold the earliest pending
     // edge, so progress never depends on new ones; a window full of blocked edges is re-examined every round, so keep it small)
-    unsigned want = nsurv < wmul * T ? wmul * T - nsurv : 0;
+    unsigned want = nsurv < wt ? wt - nsurv : 0;
     if (want > cap - nsurv) want = cap - nsurv;
     if (want > ne - next) want = ne - next;
     const unsigned n = nsurv + want;
@@ -337,7 +341,11 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       if (!retired && (e.w & MWS_ATTR) && s.cnt[a] && s.cnt[b]) retired = mws_pair_known(pairs, a, b);
       if (!retired) {
         const u64 mine = tag | (u64)(0xffffffffu - e.x);
-        atomicMax(&claim[a], mine); atomicMax(&claim[b], mine);
+        // a claim only grows within a round: a root that already holds an earlier edge needs no read-modify-write from this one.  With one giant
+        // cluster (a random-initialised network's output: half a million window entries end in the same root) every entry used to queue an
+        // atomicMax on ONE word — 7.1 of the 7.5 s of that case; the entries arrive roughly earliest first, so almost all of them now stop at the load
+        if (__hip_atomic_load(&claim[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(&claim[a], mine);
+        if (__hip_atomic_load(&claim[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < mine) atomicMax(&claim[b], mine);
       }
       e.y = (unsigned)a; e.z = (unsigned)b;
       if (retired) e.x = MWS_RETIRED;
@@ -402,6 +410,11 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       if (tid == 0) ctl->stalled = 1;
       break;
     }
+    {
+      const unsigned retired = n - ns2;
+      if ((u64)retired * 10 >= (u64)n * 9 && wt <= cap / 2) wt *= 2;
+      else if ((u64)retired * 2 < (u64)n && wt >= 2 * wmul * T) wt /= 2;
+    }
     nsurv = ns2;
     uint4* t = win; win = wout; wout = t;
   }
@@ -431,7 +444,7 @@ __global__ void mws_label_kernel(MwsState s, const unsigned char* mask, const in
     labels[i] = bad ? ~0ull : (mask && !mask[i]) ? 0ull : (u64)rank[first[s.root[i]]] + 1ull;
 }
 
-#define MWS_WIN_CAP (1u << 20)
+#define MWS_WIN_CAP (1u << 22)
 #define MWS_MAX_WGS 128
 struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_pairs, off_ops, off_win, off_keys2, off_cnt, off_state, off_pool, off_first, off_flags, off_rank, off_tmp, tmp_bytes, total; };
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }

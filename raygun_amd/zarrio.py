@@ -132,12 +132,26 @@ def blosc_decode(buf):
     return bytes(out)
 
 
+def _lz4_compress(blk):
+    """One LZ4 block by the library's host-side rg_lz4_compress_block, or None when the library is not there (then zlib is used)."""
+    try:
+        from . import _lib
+        L = _lib.lib()
+    except Exception:
+        return None
+    import ctypes as C
+    cap = int(L.rg_lz4_compress_bound(len(blk)))
+    dst = C.create_string_buffer(max(cap, 1))
+    got = L.rg_lz4_compress_block(bytes(blk), len(blk), dst, cap)
+    return None if got < 0 else dst.raw[:got]
+
+
 def blosc_encode(raw, cfg):
-    """bytes -> one Blosc (c-blosc 1.x) frame any Blosc reader decodes: the inner codec is named by the FRAME's flags, not by the
-    array's metadata, so an array whose .zarray says blosc / lz4 (zarr's and daisy.prepare_ds's default) takes frames compressed with
-    the zlib inner codec (python's stdlib; codec id 3) — byte-shuffled when the element is wider than a byte and `shuffle` is not 0,
-    blocks not split (flag 0x10), a block that does not shrink stored as is (stream size == block size), an incompressible chunk as a
-    memcpy frame (flag 0x2).  `cfg`: the compressor dict (+ "_typesize" from the array's dtype; clevel -> zlib level)."""
+    """bytes -> one Blosc (c-blosc 1.x) frame any Blosc reader decodes.  The inner codec is named by the FRAME's flags, not by the array's metadata:
+    cname lz4 / lz4hc (zarr's and daisy.prepare_ds's default) is written as LZ4 blocks by the library's host-side compressor (codec id 1: memory-speed
+    writes for predict's 34-MB destination chunks); any other cname, or a missing library, as zlib (python's stdlib; codec id 3).  Byte-shuffled when the
+    element is wider than a byte and `shuffle` is not 0, blocks not split (flag 0x10), a block that does not shrink stored as is (stream size == block size),
+    an incompressible chunk as a memcpy frame (flag 0x2).  `cfg`: the compressor dict (+ "_typesize" from the array's dtype; clevel -> zlib level)."""
     raw = bytes(raw)
     n = len(raw)
     ts = int(cfg.get("_typesize", 1))
@@ -151,6 +165,7 @@ def blosc_encode(raw, cfg):
     if n >= (1 << 31) - 16 - 4 * ((n + bs - 1) // bs + 1):
         raise ValueError("blosc: chunk too large for one frame")
     nblocks = (n + bs - 1) // bs if n else 0
+    use_lz4 = str(cfg.get("cname", "lz4")).startswith("lz4") and n > 0 and _lz4_compress(b"probe") is not None
     body, starts, pos = [], [], 16 + 4 * nblocks
     for b in range(nblocks):
         blk = raw[b * bs:(b + 1) * bs]
@@ -158,13 +173,13 @@ def blosc_encode(raw, cfg):
             a = np.frombuffer(blk, np.uint8)
             nel = len(blk) // ts
             blk = a[:nel * ts].reshape(nel, ts).T.tobytes() + bytes(a[nel * ts:])
-        c = zlib.compress(blk, level)
-        if len(c) >= len(blk):
+        c = _lz4_compress(blk) if use_lz4 else zlib.compress(blk, level)
+        if c is None or len(c) >= len(blk):
             c = blk                                   # stored stream: its size equals the block's
         starts.append(pos)
         body.append(len(c).to_bytes(4, "little") + c)
         pos += 4 + len(c)
-    flags = (0x1 if shuffle else 0) | 0x10 | (3 << 5)
+    flags = (0x1 if shuffle else 0) | 0x10 | ((1 if use_lz4 else 3) << 5)
     if pos >= n + 16:                                 # nothing gained: the stored form
         return bytes([2, 1, flags | 0x2, ts]) + n.to_bytes(4, "little") + bs.to_bytes(4, "little") + (n + 16).to_bytes(4, "little") + raw
     return (bytes([2, 1, flags, ts]) + n.to_bytes(4, "little") + bs.to_bytes(4, "little") + pos.to_bytes(4, "little")
