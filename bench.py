@@ -49,6 +49,8 @@ def parse():
                     "BASELINE config 4 is 'DDP CycleGAN + UNet'; the flag is accepted and ignored)")
     ap.add_argument("--replicas", action="store_true", help="config5 / predict / segment with --gpus N: one private volume per GPU (no exchange) instead of ONE "
                     "global volume sharded over the ranks")
+    ap.add_argument("--source", default="hbm", choices=["hbm", "zarr"], help="predict workload: the volume resident in HBM (default), or the reference's real flow — "
+                    "zarr uint8 source on disk -> block runner -> zarr uint8 destinations on disk (predict.py:111-164)")
     ap.add_argument("--cpu-size", type=int, default=0)
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N without a launcher: seconds before the supervised ranks are terminated")
     return ap.parse_args()
@@ -270,6 +272,24 @@ def main_aux(a, rank, local, world, dev):
         def step():
             # rank=0, world=1: every rank predicts ITS OWN whole volume (weak scaling), nothing is sharded a second time
             return P.predict_volume(model, vol, input_shape=[196] * 3, output_shape=[104] * 3, out_dtypes=[np.uint8, np.uint8], rank=0, world=1)
+        zarr_info = None
+        if a.source == "zarr":
+            # the reference's real flow (predict.py:70,111-125,154-164 + worker.py:94-160): a chunked uint8 source container on disk, one destination dataset per
+            # model output chunked by the write ROI (uint8: value * 255 clamped), Blosc / lz4 like daisy.prepare_ds's default; everything crosses PCIe and the disk
+            import shutil
+            import tempfile
+            from raygun_amd import zarrio
+            root = tempfile.mkdtemp(prefix=f"raygun_amd_bench_r{rank}_", dir=os.environ.get("RAYGUN_AMD_BENCH_TMP") or None)
+            path = os.path.join(root, "vol.zarr")
+            src = zarrio.prepare_ds(path, "volumes/raw", vol.shape, (4, 4, 4), np.uint8, write_size=(64, 64, 64))
+            src[...] = vol.cpu().numpy()
+            names = ["volumes/pred_affs", "volumes/pred_lsds"]
+            zarr_info = dict(container=path, source_chunks=[64] * 3, destination_chunks=[20, 104, 104, 104], compressor=src.compressor)
+
+            def step():
+                dests = P.predict_zarr(model, path, "volumes/raw", output_ds=names, out_specs={n_: {"dtype": np.uint8} for n_ in names}, input_shape=[196] * 3,
+                                       output_shape=[104] * 3, out_channels=[20, 10], rank=0, world=1)
+                return dests, nblk
     else:
         size = a.size or 256
         affs = structured_affs(size, rank, dev)
@@ -349,11 +369,20 @@ def main_aux(a, rank, local, world, dev):
         roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches_per_step=dom[1]["launches"] // a.steps,
                         avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4))
-        res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks", unit="Mvoxels/s",
+        if a.source == "zarr":
+            import shutil
+            from raygun_amd import predict as P2
+            zarr_info["combiner"] = P2.COMBINER_STATS[-2:]
+            zarr_info["bytes_on_disk"] = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(zarr_info["container"]) for f in fs)
+            shutil.rmtree(os.path.dirname(zarr_info["container"]), ignore_errors=True)
+        res = dict(metric="Mvoxels/sec block-wise predict (output voxels), 196^3 -> 104^3 blocks" + (", zarr source -> zarr destinations on disk" if a.source == "zarr" else ""),
+                   unit="Mvoxels/s",
                    dtype=os.environ.get("RAYGUN_AMD_PREDICT_PRECISION", "f16"),   # the block runner's 16-bit storage type (predict_volume's default: IEEE half)
                    config=dict(workload=f"predict {size}^3 uint8 volume per GPU in {nblk} blocks, MTLSDModel(UNet ngf12 x6 3-level valid, "
-                                        "20 affinities + 10 LSDs), uint8 destinations in HBM", parallelism=f"one volume of {nblk} blocks per GPU x{world}"),
-                   blocks_per_s=round(nblk * world / (dt / a.steps), 2))
+                                        "20 affinities + 10 LSDs), " + ("zarr uint8 source (64^3 chunks) and zarr uint8 destinations (chunks = write ROI) ON DISK, PCIe + codec + "
+                                        "file system inside the timed region" if a.source == "zarr" else "uint8 destinations in HBM"),
+                           parallelism=f"one volume of {nblk} blocks per GPU x{world}"),
+                   blocks_per_s=round(nblk * world / (dt / a.steps), 2), **({"zarr": zarr_info} if zarr_info else {}))
     res.update(value=round(units * world / (dt / a.steps) / 1e6, 3), n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic", roofline=roofline)
     if world == 1 and not a.no_cpu_baseline:

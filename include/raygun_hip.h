@@ -362,6 +362,14 @@ int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* ds
  * LZ4 block (greedy matcher, 64 KiB window); returns the compressed size or -1 when dst_cap < what the input needs (rg_lz4_compress_bound(n) always fits). */
 int64_t rg_lz4_compress_bound(int64_t n);
 int64_t rg_lz4_compress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+/* whole Blosc (c-blosc 1.x) frames, one call per chunk (the Python side releases the GIL around it): compress = lz4 inner codec, byte shuffle for
+ * typesize > 1 when shuffle != 0, unsplit blocks (blocksize 0: 256 KiB), stored form when nothing is gained; dst_cap >= rg_blosc_compress_bound(n).
+ * decompress = lz4 / lz4hc and stored frames with byte shuffle, split or unsplit: returns nbytes, -1 malformed, -2 a frame for the Python reader
+ * (bit shuffle, other inner codecs). */
+int64_t rg_blosc_compress_bound(int64_t n);
+int64_t rg_blosc_compress(const uint8_t* src, int64_t n, int32_t typesize, int32_t shuffle, int32_t blocksize, uint8_t* dst, int64_t dst_cap);
+int64_t rg_blosc_nbytes(const uint8_t* src, int64_t src_len);
+int64_t rg_blosc_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
 
 /* ---- train-time target generation of the MTLSD system (reference: src/raygun/io/MTLSDDataPipe.py:99-131; gunpowder's AddAffinities /
  * BalanceLabels and lsd's AddLocalShapeDescriptor restated — parity unpinned against those packages, oracle/targets.py).  Dense device

@@ -102,6 +102,10 @@ _SIGS = {
     "rg_lz4_decompress_block": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "rg_lz4_compress_bound": (C.c_int64, [C.c_int64]),
     "rg_lz4_compress_block": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "rg_blosc_compress_bound": (C.c_int64, [C.c_int64]),
+    "rg_blosc_compress": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "rg_blosc_nbytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "rg_blosc_decompress": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "rg_add_affinities": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, _I3, _I3, _I3, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rg_balance_labels_workspace_bytes": (C.c_int64, []),
     "rg_balance_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -284,15 +284,11 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
   const unsigned N = (unsigned)((long)Z * Y * X);
   const unsigned ne = *count;
   unsigned bar_target = 0, next = 0, nsurv = 0, pend = 0;   // pend: list operations of the previous round, applied at the head of this one
-  // Window size, adapted per round from what every thread sees alike (the survivor count): while at least 90 % of a round's entries retire the round is
-  // paid for by its two grid barriers and its chains of dependent loads, not by its entries — double the window (structured volumes: 70 rounds of
-  // 0.33 M entries become ~20 of up to 4 M); when less than half retire, entries are mostly blocked and every round re-examines them — halve it.
-  unsigned wt = wmul * T;
   uint4* win = win0; uint4* wout = win1;
   for (unsigned round = 1;; ++round) {
     // fresh edges this round: top the window up to ~2 entries per thread (the survivors already hold the earliest pending
     // edge, so progress never depends on new ones; a window full of blocked edges is re-examined every round, so keep it small)
-    unsigned want = nsurv < wt ? wt - nsurv : 0;
+    unsigned want = nsurv < wmul * T ? wmul * T - nsurv : 0;
     if (want > cap - nsurv) want = cap - nsurv;
     if (want > ne - next) want = ne - next;
     const unsigned n = nsurv + want;
@@ -410,11 +406,6 @@ __global__ __launch_bounds__(MWS_THREADS) void mws_rounds_kernel(const u64* keys
       if (tid == 0) ctl->stalled = 1;
       break;
     }
-    {
-      const unsigned retired = n - ns2;
-      if ((u64)retired * 10 >= (u64)n * 9 && wt <= cap / 2) wt *= 2;
-      else if ((u64)retired * 2 < (u64)n && wt >= 2 * wmul * T) wt /= 2;
-    }
     nsurv = ns2;
     uint4* t = win; win = wout; wout = t;
   }
@@ -444,8 +435,8 @@ __global__ void mws_label_kernel(MwsState s, const unsigned char* mask, const in
     labels[i] = bad ? ~0ull : (mask && !mask[i]) ? 0ull : (u64)rank[first[s.root[i]]] + 1ull;
 }
 
-#define MWS_WIN_CAP (1u << 22)
-#define MWS_MAX_WGS 128
+#define MWS_WIN_CAP (1u << 20)
+#define MWS_MAX_WGS 256
 struct MwsPlan { long N, ne_max, pool_nodes; size_t off_claim, off_pairs, off_ops, off_win, off_keys2, off_cnt, off_state, off_pool, off_first, off_flags, off_rank, off_tmp, tmp_bytes, total; };
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 static int mws_plan(const rg_mws_params* p, MwsPlan* q) {
@@ -555,7 +546,8 @@ static int mws_segment_src(MwsSrc affs, const int32_t* offsets, const uint8_t* m
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mws_rounds_kernel, MWS_THREADS, 0) != hipSuccess || cus * per_cu < 1)
         RG_FAIL(RG_ERR_HIP, "mws: cannot size the persistent grid");
-      wgs = cus * per_cu < MWS_MAX_WGS ? cus * per_cu : MWS_MAX_WGS;
+      const int mx = rg_opt(RG_OPT_MWS_WGS) > 0 && rg_opt(RG_OPT_MWS_WGS) <= MWS_MAX_WGS ? rg_opt(RG_OPT_MWS_WGS) : 128;
+      wgs = cus * per_cu < mx ? cus * per_cu : mx;
     }
     const u64* kp = keys2; const unsigned* cp = count; const int* op = offsets;
     u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
@@ -563,7 +555,7 @@ static int mws_segment_src(MwsSrc affs, const int32_t* offsets, const uint8_t* m
     MwsCtl* ctl = (MwsCtl*)(w + q.off_cnt + 64);
     unsigned* bar = (unsigned*)(w + q.off_cnt + 512);
     int zz = Z, yy = Y, xx = X, no = p->n_offsets, na = p->n_attractive;
-    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
+    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = rg_opt(RG_OPT_MWS_WMUL) > 0 ? (unsigned)rg_opt(RG_OPT_MWS_WMUL) : 4u;
     const unsigned* gperm = nullptr; const unsigned* geu = nullptr; const unsigned* gev = nullptr; const unsigned char* gattr = nullptr;
     void* args[] = {&kp, &cp, &op, &S, &claim, &pairs, &win0, &win1, &ops, &ctl, &zz, &yy, &xx, &no, &na, &cap, &pool_cap, &wmul,
                     &gperm, &geu, &gev, &gattr, &bar};
@@ -690,14 +682,15 @@ extern "C" int rg_mws_graph(const uint32_t* wkey, const uint64_t* gid, const uin
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
           hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mws_rounds_kernel, MWS_THREADS, 0) != hipSuccess || cus * per_cu < 1)
         RG_FAIL(RG_ERR_HIP, "mws_graph: cannot size the persistent grid");
-      wgs = cus * per_cu < MWS_MAX_WGS ? cus * per_cu : MWS_MAX_WGS;
+      const int mx = rg_opt(RG_OPT_MWS_WGS) > 0 && rg_opt(RG_OPT_MWS_WGS) <= MWS_MAX_WGS ? rg_opt(RG_OPT_MWS_WGS) : 128;
+      wgs = cus * per_cu < mx ? cus * per_cu : mx;
     }
     const u64* kp = nullptr; const unsigned* cp = count; const int* op = nullptr;
     u64* claim = (u64*)(w + q.off_claim); u64* pairs = (u64*)(w + q.off_pairs); int2* ops = (int2*)(w + q.off_ops);
     uint4* win0 = (uint4*)(w + q.off_win); uint4* win1 = (uint4*)(w + q.off_win + al((size_t)MWS_WIN_CAP * 16));
     unsigned* bar = (unsigned*)(w + q.off_ctl + 512);
     int zz = 1, yy = 1, xx = (int)q.N, no = 0, na = 0;
-    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = 4;
+    unsigned cap = MWS_WIN_CAP, pool_cap = (unsigned)q.pool_nodes, wmul = rg_opt(RG_OPT_MWS_WMUL) > 0 ? (unsigned)rg_opt(RG_OPT_MWS_WMUL) : 4u;
     const unsigned* gperm = perm; const unsigned* geu = eu; const unsigned* gev = ev; const unsigned char* gattr = attractive;
     if (hipMemsetAsync(S.pool, 0xff, (size_t)q.pool_nodes * 8, st) != hipSuccess || hipMemsetAsync(claim, 0, (size_t)q.N * 8, st) != hipSuccess ||
         hipMemsetAsync(pairs, 0, (size_t)8 << MWS_PAIR_BITS, st) != hipSuccess) RG_FAIL(RG_ERR_HIP, "mws_graph: memset failed");

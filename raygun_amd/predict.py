@@ -63,6 +63,7 @@ def _to_destination(out, dtype, on_device=False):
 
 
 FALLBACK_BLOCKS = []   # block indices the f16 runner re-ran with bf16 storage (diagnostics; appended per call)
+COMBINER_STATS = []    # per destination of the last on-disk runs: chunks written once / chunks that went through the locked read-modify-write
 NONFINITE_BLOCKS = []  # block indices whose output is inf / NaN even with bf16 storage: stored as the reference stores them, and reported
 
 
@@ -117,10 +118,30 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         scale, shift = scale * scaleShift_input[0], shift * scaleShift_input[0] + scaleShift_input[1]
     if hasattr(model, "eval"):
         model.eval()
+    # on-disk flow (blockio.py): decoded source chunks are cached across blocks, destination chunks are assembled in memory and written once
+    from . import blockio
+    use_blockio = os.environ.get("RAYGUN_AMD_BLOCKIO", "1") != "0"
+    reader_src = source
+    if use_blockio and not resident and hasattr(source, "_read_chunk") and hasattr(source, "_chunk_ranges"):
+        reader_src = blockio.ChunkCache(source)
+    combiners = []
+    if use_blockio and destinations is not None:
+        my_set = set(mine)
+        for d in destinations:
+            if hasattr(d, "_write_chunk") and hasattr(d, "_chunk_ranges"):
+                lead = tuple(d.shape[:-3])
+                def roi(b):
+                    wz, wy, wx = blocks[b]
+                    return ((0,) * len(lead) + (wz, wy, wx), lead + (wz + write[0], wy + write[1], wx + write[2]))
+                kind = blockio.DeviceChunkCombiner if np.dtype(d.dtype) in (np.dtype(np.uint8), np.dtype(np.float32)) else blockio.ChunkCombiner
+                kw = dict(device=dev) if kind is blockio.DeviceChunkCombiner else {}
+                d._combiner = kind(d, [roi(b) for b in mine], [roi(b) for b in range(len(blocks)) if b not in my_set], **kw)
+                combiners.append(d)
+
     def fetch(bi):  # host side of one block: slice (or chunk reads + decompression), contiguous, pinned
         wz, wy, wx = blocks[bi]
         rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
-        a = np.ascontiguousarray(source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]])
+        a = np.ascontiguousarray(reader_src[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]])
         return torch.from_numpy(a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))).pin_memory()
 
     n_done = 0
@@ -181,9 +202,14 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 isint = odt == np.dtype(np.uint8)
                 ops.store_block(o, view[None], 255.0 if isint else 1.0, 0.0, 255.0, flag)
                 if not resident:
-                    if state["drain"] is None:
-                        state["drain"] = _Drain(dev)
-                    state["drain"].put(tgt, dest, roi)
+                    comb = getattr(dest, "_combiner", None)
+                    if comb is not None and hasattr(comb, "dev"):       # chunk buffers in HBM: GPU copies now, one contiguous download per finished chunk (blockio.py)
+                        lead = () if tgt.dim() == 3 else (0,)
+                        comb.put(list(lead) + [wz, wy, wx], ([tgt.shape[0]] if tgt.dim() == 4 else []) + [wz + write[0], wy + write[1], wx + write[2]], tgt)
+                    else:
+                        if state["drain"] is None:
+                            state["drain"] = _Drain(dev)
+                        state["drain"].put(tgt, dest, roi)
                 continue
             o = ops.leave(o) if ops.is_cl(o) else o
             o = o.detach().float()[0]
@@ -247,11 +273,23 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 pass
         if not resident and len(mine):
             reader.shutdown(wait=False)
+        for d in combiners:
+            try:
+                d._combiner.close()
+            except BaseException:
+                pass
+            del d._combiner
         raise
     if state["drain"] is not None:
         state["drain"].close()
     if not resident and len(mine):
         reader.shutdown()
+    for d in combiners:       # every chunk this rank owns alone has been written exactly once by now (what is left are chunks of unfinished regions)
+        d._combiner.close()
+        COMBINER_STATS.append(dict(d._combiner.stats))
+        del d._combiner
+    if reader_src is not source:
+        reader_src.close()
     destinations = state["destinations"]
     return destinations, n_done
 
@@ -401,7 +439,14 @@ class _Drain:
         also page-faulted in here, which is what dominates a first pass).  Chunked on-disk destinations are written by this
         one thread (a chunk must not be read-modified-written from two threads)."""
         if not isinstance(dest, np.ndarray):
-            dest[tuple(slice(None) if w is Ellipsis else w for w in where) if dest.ndim == 4 else tuple(where[1:])] = block
+            key = tuple(slice(None) if w is Ellipsis else w for w in where) if dest.ndim == 4 else tuple(where[1:])
+            comb = getattr(dest, "_combiner", None)
+            if comb is not None:      # write-combining: the chunk goes to disk once, when its last block has arrived (blockio.py)
+                lo = [0 if k == slice(None) else k.start for k in key]
+                hi = [n if k == slice(None) else k.stop for k, n in zip(key, dest.shape)]
+                comb.put(lo, hi, block)
+            else:
+                dest[key] = block
             return
         if block.ndim == 3:
             z = block.shape[0]

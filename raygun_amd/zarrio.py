@@ -90,6 +90,17 @@ def blosc_decode(buf):
     buf = memoryview(buf)
     if len(buf) < 16:
         raise ValueError("blosc: frame shorter than its header")
+    L = _native()
+    if L is not None:     # one native call per chunk (lz4 / stored frames; ctypes drops the GIL around it): -2 = a frame for the Python decoder below
+        import ctypes as C
+        raw = bytes(buf)
+        n = int(L.rg_blosc_nbytes(raw, len(raw)))
+        out = C.create_string_buffer(max(n, 1))
+        got = int(L.rg_blosc_decompress(raw, len(raw), out, n))
+        if got == n:
+            return out.raw[:n]
+        if got != -2:
+            raise ValueError("blosc: malformed frame")
     flags, typesize = buf[2], buf[3]
     nbytes, blocksize, cbytes = (int.from_bytes(buf[4 + 4 * i:8 + 4 * i], "little") for i in range(3))
     if cbytes > len(buf):
@@ -132,6 +143,52 @@ def blosc_decode(buf):
     return bytes(out)
 
 
+_NATIVE = []
+
+
+def _native():
+    """The HIP library's host-side codecs, or None when the library is not built / loadable (pure-Python paths then)."""
+    if not _NATIVE:
+        try:
+            from . import _lib
+            _NATIVE.append(_lib.lib())
+        except Exception:
+            _NATIVE.append(None)
+    return _NATIVE[0]
+
+
+def _blosc_encode_array(arr, cfg):
+    """A contiguous ndarray -> Blosc / lz4 frame as a uint8 ndarray view (the chunk writer's fast path: no bytes copies on the Python side)."""
+    import ctypes as C
+    L = _native()
+    n = arr.nbytes
+    cap = int(L.rg_blosc_compress_bound(n))
+    dst = np.empty(cap, np.uint8)
+    ts = arr.dtype.itemsize
+    bs = int(cfg.get("blocksize", 0) or 0)
+    got = int(L.rg_blosc_compress(C.c_void_p(arr.ctypes.data), n, ts if 1 <= ts <= 255 else 1, 1 if (ts > 1 and int(cfg.get("shuffle", 1)) != 0) else 0, bs,
+                                  C.c_void_p(dst.ctypes.data), cap))
+    if got <= 0:
+        raise ValueError("blosc: native compressor failed")
+    return dst[:got]
+
+
+def _blosc_decode_array(raw, dtype):
+    """Blosc frame (bytes) -> 1-D ndarray of `dtype` decoded by the native codec, or None when the frame needs the Python decoder."""
+    import ctypes as C
+    L = _native()
+    n = int(L.rg_blosc_nbytes(raw, len(raw)))
+    if n < 0 or n % np.dtype(dtype).itemsize:
+        return None
+    out = np.empty(n, np.uint8)
+    got = int(L.rg_blosc_decompress(raw, len(raw), C.c_void_p(out.ctypes.data), n))
+    if got == -2:
+        return None
+    if got != n:
+        raise ValueError("blosc: malformed frame")
+    return out.view(dtype)
+
+
 def _lz4_compress(blk):
     """One LZ4 block by the library's host-side rg_lz4_compress_block, or None when the library is not there (then zlib is used)."""
     try:
@@ -166,6 +223,14 @@ def blosc_encode(raw, cfg):
         raise ValueError("blosc: chunk too large for one frame")
     nblocks = (n + bs - 1) // bs if n else 0
     use_lz4 = str(cfg.get("cname", "lz4")).startswith("lz4") and n > 0 and _lz4_compress(b"probe") is not None
+    if use_lz4:           # the whole frame in one native call
+        import ctypes as C
+        L = _native()
+        cap = int(L.rg_blosc_compress_bound(n))
+        dst = C.create_string_buffer(cap)
+        got = int(L.rg_blosc_compress(raw, n, ts, 1 if shuffle else 0, bs, dst, cap))
+        if got > 0:
+            return dst.raw[:got]
     body, starts, pos = [], [], 16 + 4 * nblocks
     for b in range(nblocks):
         blk = raw[b * bs:(b + 1) * bs]
@@ -300,6 +365,12 @@ class Array:
             return None
         with _fopen(p, "rb") as f:
             raw = f.read()
+        if self.compressor is not None and self.compressor.get("id") == "blosc" and _native() is not None:
+            a = _blosc_decode_array(raw, self.dtype)      # straight into the array's buffer: no intermediate bytes objects, the GIL is free meanwhile
+            if a is not None:
+                if a.size != int(np.prod(self.chunks)):
+                    raise ValueError(f"{p}: chunk holds {a.size} items, expected {int(np.prod(self.chunks))}")
+                return a.reshape(self.chunks, order=self.order)
         if self.compressor is not None:
             raw = _CODECS[self.compressor["id"]][1](raw)
         a = np.frombuffer(raw, dtype=self.dtype)
@@ -310,9 +381,16 @@ class Array:
     def _write_chunk(self, idx, data):
         p = self._chunk_path(idx)
         os.makedirs(os.path.dirname(p), exist_ok=True)
-        raw = np.asarray(data, dtype=self.dtype).tobytes(order=self.order)
-        if self.compressor is not None:
-            raw = _CODECS[self.compressor["id"]][0](raw, {**self.compressor, "_typesize": np.dtype(self.dtype).itemsize})
+        raw = None
+        if (self.compressor is not None and self.compressor.get("id") == "blosc" and str(self.compressor.get("cname", "lz4")).startswith("lz4")
+                and _native() is not None):
+            arr = np.asarray(data, dtype=self.dtype)
+            if arr.flags["C_CONTIGUOUS" if self.order == "C" else "F_CONTIGUOUS"]:
+                raw = _blosc_encode_array(arr, self.compressor)   # from the array's own buffer into one preallocated frame buffer (GIL released in between)
+        if raw is None:
+            raw = np.asarray(data, dtype=self.dtype).tobytes(order=self.order)
+            if self.compressor is not None:
+                raw = _CODECS[self.compressor["id"]][0](raw, {**self.compressor, "_typesize": np.dtype(self.dtype).itemsize})
         tmp = p + f".{os.getpid()}.tmp"
         with _fopen(tmp, "wb") as f:
             f.write(raw)
@@ -434,8 +512,8 @@ class Group:
         shape = tuple(int(v) for v in shape)
         if chunks is None:
             chunks = tuple(min(s, 64) for s in shape)
-        if compressor == "default":
-            compressor = {"id": "zlib", "level": 1}
+        if compressor == "default":   # zarr's (and daisy.prepare_ds's) own default is Blosc / lz4: written by the library's host-side codec when it is there
+            compressor = ({"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0} if _native() is not None else {"id": "zlib", "level": 1})
         meta = {"zarr_format": 2, "shape": list(shape), "chunks": [int(c) for c in chunks], "dtype": np.dtype(dtype).str,
                 "compressor": compressor, "fill_value": fill_value, "order": "C", "filters": None}
         if dimension_separator != ".":

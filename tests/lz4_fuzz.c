@@ -9,6 +9,18 @@
 extern "C"
 #endif
 int64_t rg_lz4_decompress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+#ifdef __cplusplus
+extern "C" {
+#endif
+int64_t rg_lz4_compress_bound(int64_t n);
+int64_t rg_lz4_compress_block(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+int64_t rg_blosc_compress_bound(int64_t n);
+int64_t rg_blosc_compress(const uint8_t* src, int64_t n, int32_t typesize, int32_t shuffle, int32_t blocksize, uint8_t* dst, int64_t dst_cap);
+int64_t rg_blosc_nbytes(const uint8_t* src, int64_t src_len);
+int64_t rg_blosc_decompress(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+#ifdef __cplusplus
+}
+#endif
 static uint64_t s = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 13); }
 static size_t put_len(uint8_t* o, size_t n) { size_t k = 0; while (n >= 255) { o[k++] = 255; n -= 255; } o[k++] = (uint8_t)n; return k; }
@@ -61,6 +73,35 @@ int main(void) {
     free(in); free(enc); free(out);
   }
   if (rg_lz4_decompress_block(NULL, 3, NULL, 3) != -1) return 5;
+  /* the library's own compressor and the whole-frame Blosc codec: round trips over sizes around the end-of-block rules, type sizes with and without
+   * shuffle, small block sizes (many blocks, a short last block), then truncated / bit-flipped frames and short destinations */
+  for (int rep = 0; rep < 400; ++rep) {
+    const size_t n = rep < 40 ? (size_t)rep : 1 + rnd() % 20000;
+    uint8_t* in = (uint8_t*)malloc(n ? n : 1);
+    for (size_t i = 0; i < n; ++i) in[i] = (rep % 3 == 0) ? (uint8_t)rnd() : (uint8_t)((i / 5) % 7 + (rnd() % 11 == 0));
+    const int64_t cap = rg_lz4_compress_bound((int64_t)n);
+    uint8_t* enc = (uint8_t*)malloc((size_t)cap); uint8_t* out = (uint8_t*)malloc(n ? n : 1);
+    const int64_t m = rg_lz4_compress_block(in, (int64_t)n, enc, cap);
+    if (m < 0 || rg_lz4_decompress_block(enc, m, out, (int64_t)n) != (int64_t)n || memcmp(in, out, n)) { printf("compress round trip failed (n %zu)\n", n); return 6; }
+    if (n > 64) { uint8_t* tight = (uint8_t*)malloc(n / 4); const int64_t r = rg_lz4_compress_block(in, (int64_t)n, tight, (int64_t)(n / 4)); if (r > (int64_t)(n / 4)) return 7; free(tight); }
+    const int ts = 1 + (int)(rnd() % 8), shuf = (int)(rnd() & 1), bs = (rnd() & 1) ? 0 : 16 + (int)(rnd() % 3000);
+    const int64_t fcap = rg_blosc_compress_bound((int64_t)n);
+    uint8_t* fr = (uint8_t*)malloc((size_t)fcap);
+    const int64_t fl = rg_blosc_compress(in, (int64_t)n, ts, shuf, bs, fr, fcap);
+    if (fl < 16 || fl > fcap || rg_blosc_nbytes(fr, fl) != (int64_t)n) { printf("blosc compress failed (n %zu)\n", n); return 8; }
+    if (rg_blosc_decompress(fr, fl, out, (int64_t)n) != (int64_t)n || memcmp(in, out, n)) { printf("blosc round trip failed (n %zu ts %d shuffle %d bs %d)\n", n, ts, shuf, bs); return 9; }
+    for (int k = 0; k < 12; ++k) {
+      const size_t cut = 16 + rnd() % (size_t)(fl - 16 + 1);
+      uint8_t* t = (uint8_t*)malloc(cut); memcpy(t, fr, cut);
+      if (k & 1) t[rnd() % cut] ^= (uint8_t)(1u << (rnd() % 8));
+      const size_t dcap = (k % 3 == 0) ? rnd() % (n + 1) : n;
+      uint8_t* d = (uint8_t*)malloc(dcap ? dcap : 1);
+      const int64_t r = rg_blosc_decompress(t, (int64_t)cut, d, (int64_t)dcap);
+      if (r < -2 || r > (int64_t)dcap) { printf("blosc bad return %lld\n", (long long)r); return 10; }
+      free(t); free(d);
+    }
+    free(in); free(enc); free(out); free(fr);
+  }
   printf("lz4 fuzz ok\n");
   return 0;
 }

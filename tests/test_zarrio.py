@@ -74,9 +74,14 @@ def test_writer_layout_and_partial_writes(tmp_path):
     s = zarrio.open(str(tmp_path / "v.zarr"))["seg"]
     assert s.dtype == np.uint64 and np.array_equal(s[...], ref) and s.attrs["offset"] == [1, 2, 3]
     meta = json.load(open(tmp_path / "v.zarr/seg/.zarray"))
-    assert meta["compressor"] == {"id": "zlib", "level": 1} and meta["zarr_format"] == 2
+    # the default compressor is zarr's own default (Blosc / lz4) when the library's host-side codec is there, else zlib
+    blosc = zarrio._native() is not None
+    assert meta["compressor"] == ({"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0} if blosc else {"id": "zlib", "level": 1})
+    assert meta["zarr_format"] == 2
     first = open(tmp_path / "v.zarr/seg" / ".".join(["0"] * 3), "rb").read()
-    assert np.array_equal(np.frombuffer(zlib.decompress(first), "<u8").reshape(meta["chunks"])[:5, :6, :7], ref[:meta["chunks"][0]])
+    payload = zarrio.blosc_decode(first) if blosc else zlib.decompress(first)
+    assert not blosc or (first[0] == 2 and first[3] == 8)           # a Blosc frame of 8-byte elements
+    assert np.array_equal(np.frombuffer(payload, "<u8").reshape(meta["chunks"])[:5, :6, :7], ref[:meta["chunks"][0]])
 
 
 def test_unsupported_codec_is_loud(tmp_path):
@@ -257,7 +262,7 @@ def test_blosc_encode_frames(tmp_path, dtype, cfg):
         assert nbytes == 0 or bsize <= max(nbytes, ts), "header block size beyond the buffer (c-blosc clamps it; its decompressor checks)"
         assert zarrio.blosc_decode(f) == payload
         if payload is smooth:
-            assert len(f) < len(payload) // 2 and not f[2] & 0x2
+            assert len(f) < len(payload) * (0.85 if want_codec == 1 else 0.5) and not f[2] & 0x2      # (1000-byte blocks without shuffle: LZ4 gains least)
             nblocks = (nbytes + bsize - 1) // bsize
             starts = [int.from_bytes(f[16 + 4 * b:20 + 4 * b], "little") for b in range(nblocks)]
             assert starts[0] == 16 + 4 * nblocks and starts == sorted(starts) and bool(f[2] & 0x1) == (ts > 1 and cfg.get("shuffle", 1) != 0)
@@ -314,3 +319,44 @@ def test_n5_write_round_trip_and_block_layout(tmp_path, comp):
     blk = np.frombuffer(dec(raw[20:]), dtype=">f4").reshape(3, 2, 2, 2)
     assert np.array_equal(blk, vol[:, 8:10, 10:12, 12:14])
     assert kind == ("gzip" if comp == "default" else "raw" if comp is None else comp["type"])
+
+
+def test_blockio_chunk_cache_and_write_combining(tmp_path):
+    """raygun_amd.blockio — the on-disk block runner's host side: cached source chunks give the array's own slices; block writes that straddle chunks
+    (write ROIs start at `context`) are assembled in memory and every chunk is written ONCE; chunks another rank's blocks touch go through the locked
+    read-modify-write.  Either way the container ends up as if every block had been written directly."""
+    from raygun_amd import blockio, predict as P
+    rng = np.random.default_rng(2)
+    shape = (70, 61, 64)
+    src = zarrio.prepare_ds(str(tmp_path / "s.zarr"), "raw", shape, (4, 4, 4), np.uint8, write_size=(16, 16, 16))
+    vol = rng.integers(0, 255, shape, dtype=np.uint8)
+    src[...] = vol
+    cache = blockio.ChunkCache(src, max_bytes=40 * 16 ** 3, threads=3)        # small: the LRU must evict and re-read
+    for _ in range(25):
+        lo = [int(rng.integers(0, n - 1)) for n in shape]
+        hi = [int(rng.integers(a + 1, n + 1)) for a, n in zip(lo, shape)]
+        sl = tuple(slice(a, b) for a, b in zip(lo, hi))
+        assert np.array_equal(cache[sl], vol[sl])
+    assert cache.decoded > 0
+    cache.close()
+    read, write, ctx = P.roi_geometry(3, [36] * 3, [20] * 3)
+    blocks = P.enumerate_blocks(shape, read, write, ctx)
+    data = {b: rng.integers(0, 255, (3,) + tuple(write), dtype=np.uint8) for b in blocks}
+    want = np.zeros((3,) + shape, np.uint8)
+    for (z, y, x), blk in data.items():
+        want[:, z:z + 20, y:y + 20, x:x + 20] = blk
+    roi = lambda b: ((0, b[0], b[1], b[2]), (3, b[0] + 20, b[1] + 20, b[2] + 20))      # noqa: E731
+    for name, mine in (("alone", blocks), ("shared", blocks[:len(blocks) // 2])):
+        dst = zarrio.prepare_ds(str(tmp_path / "d.zarr"), name, shape, (4, 4, 4), np.uint8, write_size=write, num_channels=3)
+        others = [b for b in blocks if b not in mine]
+        comb = blockio.ChunkCombiner(dst, [roi(b) for b in mine], [roi(b) for b in others], threads=3)
+        for b in mine:
+            comb.put(*roi(b), data[b])
+        comb.close()
+        for b in others:                                     # "the other rank": plain array writes (locked read-modify-write)
+            dst[(slice(None),) + tuple(slice(o, o + 20) for o in b)] = data[b]
+        assert np.array_equal(zarrio.open_ds(str(tmp_path / "d.zarr"), name)[...], want)
+        if name == "alone":
+            assert comb.stats["chunks_rmw"] == 0 and comb.stats["chunks_written_once"] == len(set(i for b in blocks for i in dst._chunk_ranges(*[list(v) for v in roi(b)])))
+        else:
+            assert comb.stats["chunks_rmw"] > 0 and comb.stats["chunks_written_once"] > 0
