@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: 256 CU x 4096 FLOP/clk x 2.4 GHz)
 UNET_FLOP_PER_STEP = 19.47e12  # 3 x 6.4925 TFLOP - 4.7 GFLOP (no dgrad into the raw input)
 CYC_FLOP_PER_STEP = 94.3e12    # SURVEY.md §8a train-step FLOP budget (link, identity lambda 0, 128^3)
+CYC_FLOP_IDENTITY = 140.6e12   # the reference's own default, identity lambda 0.5 (two more generator passes per step)
 
 
 def parse():
@@ -39,10 +40,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment", "config5"])
+    ap.add_argument("--workload", default="unet", choices=["unet", "cyclegan", "predict", "segment", "config5", "watershed"])
     ap.add_argument("--size", type=int, default=0, help="cube edge (default 196 unet, 128 cyclegan, 404 predict = 3^3 blocks, 256 segment)")
     ap.add_argument("--affs", default="blobs", choices=["blobs", "noise"], help="segment workload: structured affinities or pure noise (adversarial)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16"], help="unet workload: 16-bit storage type (f16 = IEEE half + dynamic loss scaling)")
+    ap.add_argument("--identity", type=float, default=0.0, help="cyclegan workload: identity-loss lambda (the reference's default config uses 0.5: two more generator passes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="unet workload: do not also time the CycleGAN 128^3 step")
     ap.add_argument("--secondary-dp", action="store_true", help="(default since round 4: every --gpus N run times the CycleGAN step data-parallel as well — "
@@ -106,7 +108,7 @@ def build_unet(dev, size, seed, precision="bf16"):
     return step, dict(model="MTLSDModel(UNet ngf12 x6 3-level valid)+WeightedMSELoss_MTLSD+Adam", params=259146829, scaler=scaler)
 
 
-def build_cyclegan(dev, size, seed):
+def build_cyclegan(dev, size, seed, precision="bf16", identity=0.0):
     import functools
     from raygun_amd import synth
     from raygun_amd.torch.systems import CycleGAN
@@ -115,7 +117,7 @@ def build_cyclegan(dev, size, seed):
                gnet_kwargs=dict(input_nc=1, ngf=64, n_blocks=6, n_downsampling=2, norm_layer=functools.partial(torch.nn.InstanceNorm3d),
                                 padding_type="same"),
                dnet_kwargs=dict(input_nc=1, ngf=64, n_layers=3, kw=4), loss_type="link",
-               loss_kwargs={"g_lambda_dict": {s: {"l1_loss": {"cycled": 10, "identity": 0}, "gan_loss": {"fake": 1, "cycled": 0}} for s in "AB"}},
+               loss_kwargs={"g_lambda_dict": {s: {"l1_loss": {"cycled": 10, "identity": identity}, "gan_loss": {"fake": 1, "cycled": 0}} for s in "AB"}},
                random_seed=None)
     s = CycleGAN(cfg)
     s.setup_networks()
@@ -127,19 +129,27 @@ def build_cyclegan(dev, size, seed):
     A = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42 + seed)).to(dev)
     B = torch.from_numpy(synth.uniform((1, 1, size, size, size), 1042 + seed)).to(dev)
 
+    import contextlib
+    from raygun_amd import amp, ops
+    scaler = amp.LossScaler() if precision == "f16" else None     # the losses own backward + step: they scale every backward and check every step through it
+    if scaler is not None:
+        s.loss.scaler = scaler
+
     def step(sync):
         holder["sync"] = sync
         s.optimizer.zero_grad()
-        fB, cB, fA, cA = s.model(real_A=A, real_B=B)
-        loss = s.loss(A, fA, cA, B, fB, cB)
+        with (ops.precision("f16") if scaler is not None else contextlib.nullcontext()):
+            fB, cB, fA, cA = s.model(real_A=A, real_B=B)
+            loss = s.loss(A, fA, cA, B, fB, cB)
         loss.backward()
         s.optimizer.step()
         return loss
 
     fused = os.environ.get("RAYGUN_AMD_FUSE_TAIL", "1") != "0"
     return step, dict(model="CycleGAN link: ResNet(ngf64,6 blocks,2 down,IN)+PatchD(ngf64,3 layers) lsgan"
+                            + (f", identity lambda {identity}" if identity else "")
                             + ("; generator tail Conv3d(64,64,7)+1x1 evaluated as one composed conv (DESIGN.md 3a)" if fused else ""),
-                      params=71848196)
+                      params=71848196, scaler=scaler)
 
 
 def pmc_traffic(kernel_name, tag="unet"):
@@ -543,6 +553,103 @@ def main_config5(a, rank, local, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def cell_affs(size, seed, device):
+    """Synthetic (3, Z, Y, X) nearest-neighbour affinities: the foreground is a union of overlapping balls (radius 10 .. 16, about 1.5 per 32^3) — so the boundary
+    distance has one maximum per ball, the watershed cuts the necks between overlapping balls and the agglomeration has touching fragments to merge — with affinity
+    0.85 .. 1.0 between two foreground voxels and 0.1 .. 0.25 elsewhere (15 % uniform noise)."""
+    g = torch.Generator(device="cpu").manual_seed(2000 + seed)
+    nb = max(4, int(1.5 * (size / 32) ** 3))
+    c = (torch.rand((nb, 3), generator=g) * size).to(device)
+    rad = (10 + 6 * torch.rand(nb, generator=g)).to(device)
+    r = torch.arange(size, device=device, dtype=torch.float32)
+    fg = torch.zeros((size,) * 3, dtype=torch.bool, device=device)
+    for i in range(nb):
+        d2 = ((r - c[i, 0]) ** 2)[:, None, None] + ((r - c[i, 1]) ** 2)[None, :, None] + ((r - c[i, 2]) ** 2)[None, None, :]
+        fg |= d2 < rad[i] ** 2
+    noise = torch.rand((3,) + (size,) * 3, generator=torch.Generator(device=device).manual_seed(3000 + seed), device=device) if device != "cpu" else \
+        torch.rand((3,) + (size,) * 3, generator=torch.Generator().manual_seed(3000 + seed))
+    return torch.stack([(fg & torch.roll(fg, 1, ax)).float() for ax in range(3)]) * 0.75 + 0.1 + 0.15 * noise
+
+
+def main_watershed(a, rank, local, world, dev):
+    """--workload watershed: the reference's DEFAULT raygun-segment route (segment.py:116-136 get_segmentation with its default thresholds 0.1 .. 0.8) on a
+    synthetic (3, S, S, S) affinity volume resident in HBM: mask -> exact EDT -> seeds -> seeded watershed -> region graph -> agglomeration (host) -> one
+    relabelled uint64 volume per threshold, all left on the device.  value = input Mvoxels/s; stage times from HIP events (the agglomeration is host time)."""
+    import numpy as np
+    from raygun_amd import watershed as W
+    size = a.size or 256
+    affs = cell_affs(size, rank, dev)
+    thresholds = [float(t) for t in np.arange(0.1, 0.9, 0.1)]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step(marks=None):
+        ev = lambda: (lambda e: (e.record(), e)[1])(torch.cuda.Event(enable_timing=True))   # noqa: E731
+        t = [ev()]
+        bm = W.boundary_mask(affs, 1.0, dev); d2 = W.squared_distance_transform(bm, dev); t.append(ev())
+        seeds, n = W.seeds_from_distance(d2, 10); t.append(ev())
+        st = {}
+        frag = W.flood(d2, seeds, bm, st); t.append(ev())
+        h0 = time.perf_counter()
+        ast = {}
+        segs = list(W.agglomerate(affs, frag, thresholds, as_tensor=True, device=dev, stats=ast)); t.append(ev())
+        if marks is not None:
+            torch.cuda.synchronize()
+            marks.append(dict(mask_edt_ms=t[0].elapsed_time(t[1]), seeds_ms=t[1].elapsed_time(t[2]), flood_ms=t[2].elapsed_time(t[3]),
+                              region_graph_agglomerate_relabel_ms=(time.perf_counter() - h0) * 1e3, flood_rounds=st["rounds"], seeds=n, **ast))
+        return segs
+    for _ in range(max(1, a.warmup)):
+        segs = step()
+    barrier()
+    marks = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        segs = step(marks)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        if rank != 0:
+            torch.distributed.destroy_process_group()
+            return
+    ms = dt / a.steps * 1e3
+    stages = {k: round(float(np.median([m[k] for m in marks])), 3) for k in marks[0] if k.endswith("_ms")}
+    frag_ms = stages["mask_edt_ms"] + stages["seeds_ms"] + stages["flood_ms"]
+    alg = size ** 3 * 16          # 3 float32 affinity channels read + one int32 fragment id written per voxel
+    res = dict(metric="Mvoxels/sec default raygun-segment route (seeded watershed + agglomeration, 8 thresholds)", value=round(size ** 3 * world / (dt / a.steps) / 1e6, 2),
+               unit="Mvoxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32 affinities / i32 squared distances / i32 union-find", data="synthetic",
+               config=dict(workload=f"watershed {size}^3 per GPU: synthetic 3-channel cell affinities, segment.py:116-136 get_segmentation, thresholds 0.1 .. 0.8, "
+                                    "segmentations left in HBM", parallelism=f"replicas x{world}"),
+               stages_ms=stages, fragments=marks[-1]["fragments"], seeds=marks[-1]["seeds"], flood_rounds=marks[-1]["flood_rounds"], region_graph_records=marks[-1]["records"],
+               segments_per_threshold=[int(torch.unique(s_).numel()) - 1 for s_ in segs],
+               roofline=dict(bound="hbm", kernel="fragments (ws_mask + ws_edt + ws_maxfilter + ws_ccl + ws_flood passes)", achieved=round(alg / (frag_ms * 1e-3) / 1e9, 2),
+                             peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / (frag_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), traffic=None, avg_launch_ms=round(frag_ms, 3),
+                             note="algorithmic bytes = 16 B/voxel (3 fp32 affinities in, 1 int32 fragment id out); the stage is ~25 streaming passes over 4-byte arrays "
+                                  "(3 EDT, 4 max filter, 7 labelling, 4 per flood round)"))
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            from oracle import watershed as OW
+            cs = a.cpu_size or 128
+            ca = cell_affs(cs, 0, "cpu").numpy()
+            t1 = time.time()
+            OW.get_segmentation(ca, thresholds, max_affinity_value=1.0)
+            ct = time.time() - t1
+            res["cpu_baseline"] = dict(value=round(cs ** 3 / ct / 1e6, 3), unit="Mvoxels/s", cores=1, kind="port",
+                                       sample=f"oracle/watershed.py (scipy EDT / maximum_filter / label + the C restatement of the build-defined flood + the Python "
+                                              f"restatement of waterz's merging) on the same synthetic affinities at {cs}^3: {ct:.1f} s")
+        except Exception as e:
+            res["cpu_baseline"] = dict(error=repr(e))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def cpu_baseline_aux(workload, size):
     import numpy as np
     cores, cpu = host_cpu()
@@ -576,13 +683,13 @@ def launch_ranks(a):
     return launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.rank_timeout)
 
 
-def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf16"):
+def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf16", identity=0.0):
     """Time `steps` train steps of `workload` ('unet' | 'cyclegan') after `warmup` untimed ones: barrier + synchronize on both
     sides, MAX over ranks.  Returns the result dict (rank 0) or None."""
     import contextlib
     from raygun_amd import ops, parallel
     with contextlib.redirect_stdout(sys.stderr):  # init_weights prints like the reference's; stdout carries the JSON line only
-        step, info = build_unet(dev, size, seed=rank, precision=precision) if workload == "unet" else build_cyclegan(dev, size, seed=rank)
+        step, info = build_unet(dev, size, seed=rank, precision=precision) if workload == "unet" else build_cyclegan(dev, size, seed=rank, precision=precision, identity=identity)
     sync = parallel.GradSync(prescaled=(workload == "unet"), timing=world > 1)   # algo: RAYGUN_AMD_GRADSYNC = allreduce (default) | rs_ag
     # The interpreter's full (generation-2) garbage collection walks every object the imports created — ~70 ms on this image — and,
     # landing in a timed step while the host is less than that ahead of the GPU, shows up as one 80-ms step (tools/step_trend.py).
@@ -652,7 +759,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
                         traffic_note="HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE) from the committed profiles/*_pmc_*.csv passes of this workload",
                         launches_per_step=dom[1]["launches"] // dsteps, avg_launch_ms=round(dom[1]["ms"] / dom[1]["launches"], 4),
                         measured="HIP events around this kernel's launches inside the timed region; the `kernels` table is the fully instrumented last warm-up step")
-    flop = (UNET_FLOP_PER_STEP if workload == "unet" else CYC_FLOP_PER_STEP) * (size / (196 if workload == "unet" else 128)) ** 3
+    flop = (UNET_FLOP_PER_STEP if workload == "unet" else (CYC_FLOP_IDENTITY if identity else CYC_FLOP_PER_STEP)) * (size / (196 if workload == "unet" else 128)) ** 3
     executed = sum(v["flops"] for v in tab.values()) / tsteps  # what the conv / weight-gradient launches actually multiplied
     res = dict(metric=f"Mvoxels/sec 3D UNet fwd+bwd 196^3 {precision}" if workload == "unet" else "CycleGAN 128^3 train-step ms",
                value=round(size ** 3 * world / (dt / steps) / 1e6, 3) if workload == "unet" else round(ms, 3),
@@ -697,10 +804,10 @@ def main():
         return main_config5(a, rank, local, world, dev)
     if a.workload in ("predict", "segment"):
         return main_aux(a, rank, local, world, dev)
+    if a.workload == "watershed":
+        return main_watershed(a, rank, local, world, dev)
     size = a.size or (196 if a.workload == "unet" else 128)
-    if a.precision == "f16" and a.workload != "unet":
-        raise SystemExit("bench.py: --precision f16 is the U-Net workload's (the CycleGAN losses own backward and step: bf16)")
-    res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev, precision=a.precision)
+    res = run_train(a, a.workload, size, a.steps, a.warmup, rank, world, dev, precision=a.precision, identity=a.identity if a.workload == "cyclegan" else 0.0)
     if a.workload == "unet" and a.precision == "bf16" and world == 1 and not a.no_secondary:
         # the same step with IEEE-half storage and dynamic loss scaling: the mode whose trained precision meets north_star's 1e-3
         # (DESIGN.md 4); reported beside the bf16 headline, never instead of it
@@ -728,6 +835,18 @@ def main():
                                     roofline={k: sec["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms")}
                                     if sec["roofline"] else None, comm=sec["comm"], n_gpus=sec["n_gpus"],
                                     kernel_launches_per_step=sum(k["launches"] for k in sec["kernels"].values()))
+        if world == 1:
+            # SURVEY 8d config 2 asks for the identity-0.5 variant (the reference's own default_cycleGAN_conf.json) beside the headline configuration, and the
+            # f16-storage step with dynamic loss scaling (the mode whose precision meets north_star's 1e-3): shorter runs, same line
+            for key, kw in (("identity_0.5", dict(identity=0.5)), ("f16_storage", dict(precision="f16"))):
+                gc.collect(); torch.cuda.empty_cache()
+                v = run_train(a, "cyclegan", 128, max(3, a.steps // 2), 3, rank, world, dev, **kw)
+                if res is not None and v is not None and "secondary" in res:
+                    res["secondary"][key] = dict(ms_per_step=v["ms_per_step"], ms_per_step_median=v["ms_per_step_median"], steps=v["steps"], warmup=v["warmup"],
+                                                 algorithmic_tflop_per_step=v["algorithmic_tflop_per_step"], algorithmic_tflops=v["step_tflops"],
+                                                 executed_tflop_per_step=v["executed_tflop_per_step"], workload=v["config"]["workload"],
+                                                 **({k: v[k] for k in ("loss_scale", "skipped_steps") if k in v}))
+                del v
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()

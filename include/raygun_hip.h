@@ -254,6 +254,12 @@ int rg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
  * same pass; `packed` must have been produced by rg_pack_weights with `pp` before (its pad entries are kept). */
 int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int32_t step, float grad_scale, void* packed, const rg_pack_params* pp, rg_stream s);
+/* the same update for n_items tensors in ONE launch per 24 tensors (torch.optim.Adam(params) over a whole network: systems/CycleGAN.py:167-184 builds
+ * optimisers over four networks = 96 tensors): arrays of n_items pointers / element counts; packed[i] / pp[i] may be NULL per tensor (or the arrays NULL);
+ * one set of hyper-parameters and one step count for all. */
+int rg_adam_step_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
+                       const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                       float grad_scale, rg_stream s);
 
 /* ---- loss-scaled f16-storage training (no reference counterpart: the reference trains in fp32; torch.cuda.amp.GradScaler's
  * "unscale and look for inf" step without the unscale pass — rg_adam_step takes 1/scale as grad_scale).

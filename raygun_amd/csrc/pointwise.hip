@@ -1186,6 +1186,75 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[q] = pi; m[q] = mi; v[q] = vi;
   }
 }
+// ---- multi-tensor form: ONE launch updates up to ADAM_MT tensors (the U-Net has 32 parameter tensors, the CycleGAN's four networks 96: a launch per tensor
+// is ~5 us of dispatch per few-KB bias).  The item table travels by value in the kernel arguments; a workgroup finds its item by a scan of the
+// (at most 24-entry) block prefix.  Same arithmetic, element by element, as adam_kernel.
+#define ADAM_MT 24
+struct AdamItem { float* p; const float* g; float* m; float* v; long n; AdamPack pk; int vec; int blk0; };
+struct AdamTable { AdamItem it[ADAM_MT]; int n_items; int nblocks; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable T, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  int k = 0;
+  while (k + 1 < T.n_items && (int)blockIdx.x >= T.it[k + 1].blk0) ++k;
+  const AdamItem& I = T.it[k];
+  const int nb = (k + 1 < T.n_items ? T.it[k + 1].blk0 : T.nblocks) - I.blk0;
+  const long tid = (long)((int)blockIdx.x - I.blk0) * 256 + threadIdx.x, nthr = (long)nb * 256;
+  const long n4 = I.vec ? I.n / 4 : 0;
+  for (long i = tid; i < n4; i += nthr) {
+    float4 pp = ((float4*)I.p)[i], mm = ((float4*)I.m)[i], vv = ((float4*)I.v)[i];
+    const float4 gg = ((const float4*)I.g)[i];
+    adam_four(pp, gg, mm, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    ((float4*)I.p)[i] = pp; ((float4*)I.m)[i] = mm; ((float4*)I.v)[i] = vv;
+    if (I.pk.out) *(bf16x4*)adam_pack_addr(I.pk, (unsigned)(i * 4)) = (bf16x4){(short)f2bf(pp.x), (short)f2bf(pp.y), (short)f2bf(pp.z), (short)f2bf(pp.w)};
+  }
+  for (long q = n4 * 4 + tid; q < I.n; q += nthr) {
+    float pi = I.p[q], mi = I.m[q], vi = I.v[q];
+    adam_one(pi, I.g[q], mi, vi, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+    I.p[q] = pi; I.m[q] = mi; I.v[q] = vi;
+  }
+}
+static int adam_pack_of(void* packed, const rg_pack_params* pp, int64_t n, AdamPack* pk) {
+  memset(pk, 0, sizeof(*pk));
+  if (!packed) return RG_OK;
+  int rows, red;
+  if (!pp || pack_dims(pp, &rows, &red) || !pp->src_channels_last || pp->swap || (red & 3) || (((uintptr_t)packed) & 7))
+    RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: needs a channels-last source, swap = 0 and a reduced channel count that is a multiple of 4");
+  for (int d = 0; d < 3; ++d) if (pp->ntap[d] != pp->K[d] || pp->k0[d] != 0 || pp->kstep[d] != 1) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: full tap set only");
+  if ((int64_t)rows * pp->K[0] * pp->K[1] * pp->K[2] * red != n) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: packing parameters do not match n");
+  pk->out = (bf16_t*)packed; pk->red = red; pk->red32 = round_up(red, pack_align(pp)); pk->ntap = pp->K[0] * pp->K[1] * pp->K[2];
+  pk->rowlen = pack_rowlen(pp, red);
+  return RG_OK;
+}
+// items: n_items x { p, g, m, v, packed (or NULL), pack params (or NULL) } with n[i] elements each; one set of hyper-parameters and ONE step count for all
+extern "C" int rg_adam_step_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
+                                  const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                  float grad_scale, rg_stream s) {
+  if (n_items < 0 || step < 1 || (n_items && (!p || !g || !m || !v || !n))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_multi: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  int done = 0;
+  while (done < n_items) {
+    AdamTable T; memset(&T, 0, sizeof(T));
+    int blocks = 0;
+    while (done < n_items && T.n_items < ADAM_MT) {
+      const int i = done++;
+      if (n[i] == 0) continue;
+      if (!p[i] || !g[i] || !m[i] || !v[i] || n[i] < 0) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_multi: null tensor %d", i);
+      AdamItem& I = T.it[T.n_items];
+      I.p = p[i]; I.g = g[i]; I.m = m[i]; I.v = v[i]; I.n = n[i];
+      int rc = adam_pack_of(packed ? packed[i] : nullptr, pp ? pp[i] : nullptr, n[i], &I.pk);
+      if (rc) return rc;
+      I.vec = ((((uintptr_t)p[i]) | ((uintptr_t)g[i]) | ((uintptr_t)m[i]) | ((uintptr_t)v[i])) & 15) == 0;
+      if (I.pk.out && (!I.vec || (n[i] & 3) || n[i] >= (1LL << 32))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_pack: 16-byte aligned tensors with a multiple of 4 (and fewer than 2^32) elements expected");
+      I.blk0 = blocks;
+      blocks += grid_for(I.vec ? (n[i] + 3) / 4 : n[i], 256, 8192);
+      ++T.n_items;
+    }
+    if (!T.n_items) break;
+    T.nblocks = blocks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, T, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    RG_CHECK_LAUNCH();
+  }
+  return RG_OK;
+}
 // any non-finite value in g -> *flag = 1 (never cleared here: one flag collects all the gradient tensors of a step).  Loss-scaled
 // f16-storage training (raygun_amd/amp.py): an activation gradient that left half's range reaches the weight gradients as inf / NaN.
 __global__ __launch_bounds__(256) void nonfinite_kernel(const float* g, long n, float* flag, int vec) {

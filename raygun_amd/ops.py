@@ -1533,3 +1533,37 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
                                        C.c_void_p(v.data_ptr()), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                        grad_scale, _stream()), "rg_adam_step")
     return None
+
+
+def adam_step_multi_(items, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """adam_step_ for a list of (p, g, m, v) in ONE launch per 24 tensors (rg_adam_step_multi).  Returns, per item, the refreshed forward-pack record or None
+    (as adam_step_ does).  All tensors must be dense fp32 of one layout per item; 16-bit forward packs of ONE storage type (mixed types: two calls)."""
+    n = len(items)
+    if n == 0:
+        return []
+    fwds = []
+    for p, g, m, v in items:
+        cache = getattr(p, "_rg_pack_cache", None)
+        fwd = None
+        if cache is not None and cache.get("ver") == (p._version, p.data_ptr()) and os.environ.get("RAYGUN_AMD_ADAM_PACK", "1") != "0":
+            fwd = cache.get("fwd_pack_f16") or cache.get("fwd_pack")
+        fwds.append(fwd)
+    kinds = {_KIND[f[0].dtype] for f in fwds if f is not None}
+    if len(kinds) > 1:      # (never in practice: a network trains in one storage type)
+        out = [None] * n
+        for kind in kinds:
+            idx = [i for i, f in enumerate(fwds) if f is not None and _KIND[f[0].dtype] == kind]
+            for i, r in zip(idx, adam_step_multi_([items[i] for i in idx], lr, beta1, beta2, eps, weight_decay, step, grad_scale)):
+                out[i] = r
+        rest = [i for i, f in enumerate(fwds) if f is None]
+        adam_step_multi_([items[i] for i in rest], lr, beta1, beta2, eps, weight_decay, step, grad_scale)
+        return out
+    L = _lib.lib(kinds.pop() if kinds else "bf16")
+    VP, I64 = C.c_void_p * n, C.c_int64 * n
+    P = VP(*[p.data_ptr() for p, _, _, _ in items]); G = VP(*[g.data_ptr() for _, g, _, _ in items])
+    M = VP(*[m.data_ptr() for _, _, m, _ in items]); V = VP(*[v.data_ptr() for _, _, _, v in items])
+    N = I64(*[p.numel() for p, _, _, _ in items])
+    PK = VP(*[(f[0].data_ptr() if f is not None else None) for f in fwds])
+    PP = VP(*[(C.addressof(f[1]) if f is not None else None) for f in fwds])
+    _lib.check(L.rg_adam_step_multi(P, G, M, V, N, PK, PP, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "rg_adam_step_multi")
+    return fwds

@@ -1,4 +1,4 @@
-"""torch.optim.Adam semantics on the fused HIP kernel (rg_adam_step): one launch per parameter tensor, state keys
+"""torch.optim.Adam semantics on the fused HIP kernel (rg_adam_step_multi): one launch per 24 parameter tensors, state keys
 (step / exp_avg / exp_avg_sq) identical to torch's so optimizer state_dicts interchange.
 Reference call site: optimizers/utils.py:4-9 -> torch.optim.Adam(params, **optim_kwargs) (systems/CycleGAN.py:167-184)."""
 import torch
@@ -22,6 +22,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            batches = {}      # step count -> [(p, g, exp_avg, exp_avg_sq)]: one multi-tensor launch per 24 tensors that share the hyper-parameters
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -43,10 +44,12 @@ class FusedAdam(torch.optim.Optimizer):
                 for k in ("exp_avg", "exp_avg_sq"):
                     if st[k].stride() != p.stride():  # e.g. a state dict loaded from a contiguous checkpoint
                         st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
-                fwd = ops.adam_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
-                                     group["weight_decay"], int(st["step"]), float(self.grad_scale))
-                # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
-                torch.autograd.graph.increment_version(p)
-                if fwd is not None:  # the forward operand was refreshed in the same pass: it is current for the new version
-                    p._rg_pack_cache = {"ver": (p._version, p.data_ptr()), fwd[2]: fwd[0], ("fwd_pack" if len(fwd[2]) == 4 else "fwd_pack_f16"): fwd}
+                batches.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            for step, items in batches.items():
+                fwds = ops.adam_step_multi_(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, float(self.grad_scale))
+                for (p, _, _, _), fwd in zip(items, fwds):
+                    # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
+                    torch.autograd.graph.increment_version(p)
+                    if fwd is not None:  # the forward operand was refreshed in the same pass: it is current for the new version
+                        p._rg_pack_cache = {"ver": (p._version, p.data_ptr()), fwd[2]: fwd[0], ("fwd_pack" if len(fwd[2]) == 4 else "fwd_pack_f16"): fwd}
         return loss
