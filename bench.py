@@ -158,6 +158,7 @@ def pmc_traffic(kernel_name, tag="unet"):
     tallies 128-byte read requests at 64 B).  None when no profile names this kernel."""
     import csv
     import glob
+    kernel_name = kernel_name.replace("wgrad_gemm_", "")    # the GEMM form of the weight gradient is igemm5_kernel<0, FN, 1> in rocprofv3's table
     key = kernel_name.split("<")[0]
     args = kernel_name[len(key):].strip("<>").split(",") if "<" in kernel_name else []
     out = {}

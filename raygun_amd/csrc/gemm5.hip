@@ -56,7 +56,7 @@ __device__ __forceinline__ void g5for(F&& f) { g5_impl(f, std::make_integer_sequ
 // (zeros).  rg_gemm_batched's problems are the 1x1x1-tap case with a batch index in the grid.
 // FN = 16-column fragments per wave: 9 (144-column halves, 288-column tiles: the U-Net's 432 / 2592 / 3456-channel layers) or 8 (128-column
 // halves, 256-column tiles: the CycleGAN's 256-channel ResNet blocks).
-template <bool CHECK, int FN>
+template <bool CHECK, int FN, bool RAW = false>   // RAW: the weight-gradient form (raw fp32 tiles into the caller's matrix; its own instantiation = its own name in profiles)
 __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   constexpr int G5_BN = 2 * FN * 16, NB = (G5_BN + 63) / 64;   // columns per tile, B DMA instructions per thread and K-tile
   extern __shared__ __attribute__((aligned(128))) unsigned char g5_lds[];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   if (!wn) __builtin_amdgcn_s_barrier();     // matches the trailing group's extra barrier
 
   // ---- epilogue: lane holds columns c .. c+3 of row (lane & 15) of every fragment
-  if (a.raw) {          // raw fp32 tile straight into the caller's matrix (the weight gradient: row = output channel, column = input channel of one tap)
+  if constexpr (RAW) {  // raw fp32 tile straight into the caller's matrix (the weight gradient: row = output channel, column = input channel of one tap)
     float* const obase = a.raw + batch * a.raw_batch;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -450,13 +450,13 @@ int rg_launch_wgrad_gemm(const CL5& G, const CL5& X, const rg_conv_params* p, fl
   a.tiles_n = (a.wrows + bn - 1) / bn;
   static rg_device_latch attr;
   rg_once_per_device(&attr, [] {
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
   });
-  rg_set_kernel_name("wgrad_gemm[igemm5_kernel<0,%d>]", pl.fn);
+  rg_set_kernel_name("wgrad_gemm_igemm5_kernel<0,%d,1>", pl.fn);
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.nbatch));
-  if (pl.fn == 9) hipLaunchKernelGGL((igemm5_kernel<false, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
-  else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  if (pl.fn == 9) hipLaunchKernelGGL((igemm5_kernel<false, 9, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  else hipLaunchKernelGGL((igemm5_kernel<false, 8, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
   rg_prof_mark(st);
   return RG_OK;
 }
