@@ -83,7 +83,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(256) void ws_edt_axis_kernel(const int* in, int* out, long N, int X, long stride, int extent) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  const int q = (int)((u / stride) % extent);
+  const int q = (int)(((unsigned)u / (unsigned)stride) % (unsigned)extent);      // (N < 2^31: 32-bit divisions; a 64-bit one costs ~100 instructions per voxel)
   auto f = [&](long idx) -> long { const long v = in[idx]; return FIRST ? v * v : v; };   // the first axis pass squares the 1-D distances
   long best = f(u);
   for (int k = 1; (long)k * k < best && k < extent; ++k) {
@@ -120,7 +120,7 @@ __device__ __forceinline__ int ws_reflect(int i, int n) {
 __global__ __launch_bounds__(256) void ws_maxfilter_axis_kernel(const int* in, int* out, long N, long stride, int extent, int size) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
-  const int q = (int)((u / stride) % extent);
+  const int q = (int)(((unsigned)u / (unsigned)stride) % (unsigned)extent);
   const long base = u - (long)q * stride;
   int m = INT32_MIN;
   for (int k = -(size / 2); k < size - size / 2; ++k) { const int v = in[base + (long)ws_reflect(q + k, extent) * stride]; m = v > m ? v : m; }
@@ -159,17 +159,38 @@ __device__ void ws_union(int* parent, int a, int b) {         // lock-free: the 
     a = old;                                                   // somebody hooked a elsewhere in between: continue from there
   }
 }
-__global__ __launch_bounds__(256) void ws_ccl_init_kernel(const unsigned char* fg, int* parent, long N) {
-  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < N) parent[u] = fg[u] ? (int)u : -1;
+// parent[u] = first voxel of u's run of foreground voxels along x (one wave per row: a max-scan of the run starts) — the x unions without a single atomic;
+// with the all-background regions of a boundary mask (one giant component of `maxima`) the lock-free unions of every voxel with its x neighbour were 2 of the
+// route's 9 ms, all contention on a handful of roots
+__global__ __launch_bounds__(256) void ws_ccl_init_kernel(const unsigned char* fg, int* parent, long rows, int X) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned char* m = fg + row * X;
+  int* out = parent + row * X;
+  int carry = -1;                                              // run start carried over from the previous 64 voxels (-1: the previous voxel is background)
+  for (int x0 = 0; x0 < X; x0 += 64) {
+    const int x = x0 + lane;
+    const bool on = x < X && m[x];
+    const bool prev_on = x > 0 && x < X && m[x - 1];
+    int start = on && !prev_on ? x : -1;                        // a run starts here
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(start, o); if (lane >= o) start = max(start, t); }
+    if (start < 0) start = carry;                               // no run start in this chunk up to x: the run (if any) began earlier
+    if (x < X) out[x] = on ? (int)(row * X) + start : -1;
+    carry = __shfl(on ? start : -1, 63);                        // (lane 63 beyond X in the last chunk: unused)
+  }
 }
 __global__ __launch_bounds__(256) void ws_ccl_merge_kernel(const unsigned char* fg, int* parent, long N, int Y, int X) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N || !fg[u]) return;
-  const int x = (int)(u % X), y = (int)((u / X) % Y);
-  if (x > 0 && fg[u - 1]) ws_union(parent, (int)u, (int)(u - 1));
-  if (y > 0 && fg[u - X]) ws_union(parent, (int)u, (int)(u - X));
-  if (u >= (long)Y * X && fg[u - (long)Y * X]) ws_union(parent, (int)u, (int)(u - (long)Y * X));
+  const int x = (int)((unsigned)u % (unsigned)X), y = (int)(((unsigned)u / (unsigned)X) % (unsigned)Y);
+  // x neighbours are joined already (runs).  A y / z neighbour pair needs a union only where one of the two runs STARTS: elsewhere the pair to the left
+  // (same two runs) has made it
+  const bool start = x == 0 || !fg[u - 1];
+  if (y > 0 && fg[u - X] && (start || !fg[u - X - 1])) ws_union(parent, (int)u, (int)(u - X));
+  const long YX = (long)Y * X;
+  if (u >= YX && fg[u - YX] && (start || !fg[u - YX - 1])) ws_union(parent, (int)u, (int)(u - YX));
 }
 // root of a component = its smallest voxel index = its first voxel in raster order: rank among the roots = scipy's label
 __global__ __launch_bounds__(256) void ws_ccl_flag_kernel(int* parent, int* flag, long N) {
@@ -196,11 +217,16 @@ __global__ __launch_bounds__(256) void ws_scan_sums_kernel(const int* flag, int*
   for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
 }
-__global__ void ws_scan_offsets_kernel(int* sums, int nchunks, int* total) {   // one thread: nchunks = N / 4096 (a 1024^3 volume: 262144 additions)
-  if (threadIdx.x || blockIdx.x) return;
-  int acc = 0;
-  for (int i = 0; i < nchunks; ++i) { const int v = sums[i]; sums[i] = acc; acc += v; }
-  *total = acc;
+__global__ __launch_bounds__(1024) void ws_scan_offsets_kernel(int* sums, int nchunks, int* total) {   // one workgroup: exclusive scan of the chunk sums in place
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, per = (nchunks + 1023) / 1024, lo = tid * per, hi = min(lo + per, nchunks);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += sums[i];
+  part[tid] = s; __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) { const int t = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += t; __syncthreads(); }
+  int acc = part[tid] - s;                                      // exclusive prefix of this thread's slice
+  for (int i = lo; i < hi; ++i) { const int v = sums[i]; sums[i] = acc; acc += v; }
+  if (tid == 1023) *total = part[1023];
 }
 __global__ __launch_bounds__(256) void ws_scan_apply_kernel(const int* flag, const int* sums, int* rank, long N) {
   __shared__ int part[256];
@@ -231,11 +257,11 @@ extern "C" int rg_ws_label(const uint8_t* fg, const int32_t* shape, int32_t* lab
   hipStream_t st = (hipStream_t)s;
   const dim3 grid((unsigned)((N + 255) / 256));
   rg_set_kernel_name("ws_ccl");
-  hipLaunchKernelGGL(ws_ccl_init_kernel, grid, dim3(256), 0, st, fg, parent, N);
+  hipLaunchKernelGGL(ws_ccl_init_kernel, dim3((unsigned)((Z * Y + 3) / 4)), dim3(256), 0, st, fg, parent, Z * Y, (int)X);
   hipLaunchKernelGGL(ws_ccl_merge_kernel, grid, dim3(256), 0, st, fg, parent, N, (int)Y, (int)X);
   hipLaunchKernelGGL(ws_ccl_flag_kernel, grid, dim3(256), 0, st, parent, flag, N);
   hipLaunchKernelGGL(ws_scan_sums_kernel, dim3(nchunks), dim3(256), 0, st, (const int*)flag, sums, N);
-  hipLaunchKernelGGL(ws_scan_offsets_kernel, dim3(1), dim3(64), 0, st, sums, nchunks, n_out);
+  hipLaunchKernelGGL(ws_scan_offsets_kernel, dim3(1), dim3(1024), 0, st, sums, nchunks, n_out);
   hipLaunchKernelGGL(ws_scan_apply_kernel, dim3(nchunks), dim3(256), 0, st, (const int*)flag, (const int*)sums, rank, N);
   hipLaunchKernelGGL(ws_ccl_label_kernel, grid, dim3(256), 0, st, (const int*)parent, (const int*)rank, labels, N);
   RG_CHECK_LAUNCH();
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(256) void ws_flood_pick1_kernel(WsFlood f) {
   if (!f.mask[u]) return;
   const int r = f.parent[u];                                                // flattened: the root
   if (f.seed[r]) return;                                                    // seeded clusters never pick: they are the virtual root's side of every cut
-  const int x = (int)(u % f.X), y = (int)((u / f.X) % f.Y);
+  const int x = (int)((unsigned)u % (unsigned)f.X), y = (int)(((unsigned)u / (unsigned)f.X) % (unsigned)f.Y);
   const long YX = (long)f.Y * f.X;
   const int dv = f.d2[u];
   unsigned long long k1 = WS_NONE, kid = WS_NONE;
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(256) void ws_rag_count_kernel(const int* frag, long
   if (u < N) {
     const int a = frag[u];
     if (a) {
-      const int x = (int)(u % X), y = (int)((u / X) % Y);
+      const int x = (int)((unsigned)u % (unsigned)X), y = (int)(((unsigned)u / (unsigned)X) % (unsigned)Y);
       const long YX = (long)Y * X;
       if (u >= YX) { const int b = frag[u - YX]; c += b && b != a; }
       if (y > 0) { const int b = frag[u - X]; c += b && b != a; }
@@ -388,23 +414,33 @@ __global__ __launch_bounds__(256) void ws_rag_count_kernel(const int* frag, long
 __global__ __launch_bounds__(256) void ws_rag_emit_kernel(const int* frag, const float* affs, long N, int Y, int X, unsigned long long* keys,
                                                          unsigned long long* cursor, unsigned long long cap) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= N) return;
-  const int a = frag[u];
-  if (!a) return;
-  const int x = (int)(u % X), y = (int)((u / X) % Y);
-  const long YX = (long)Y * X;
-  auto emit = [&](long nb, int axis) {
-    const int b = frag[nb];
-    if (!b || b == a) return;
-    const unsigned long long lo = (unsigned long long)(a < b ? a : b), hi = (unsigned long long)(a < b ? b : a);
-    int bin = (int)__fmul_rn(affs[(long)axis * N + u], 255.0f);              // (int)(affinity * (Bins - 1)), float32
-    bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
-    const unsigned long long slot = atomicAdd(cursor, 1ull);
-    if (slot < cap) keys[slot] = (lo << 36) | (hi << 8) | (unsigned long long)bin;
-  };
-  if (u >= YX) emit(u - YX, 0);
-  if (y > 0) emit(u - X, 1);
-  if (x > 0) emit(u - 1, 2);
+  unsigned long long rec[3]; int nrec = 0;
+  if (u < N) {
+    const int a = frag[u];
+    if (a) {
+      const int x = (int)((unsigned)u % (unsigned)X), y = (int)(((unsigned)u / (unsigned)X) % (unsigned)Y);
+      const long YX = (long)Y * X;
+      auto emit = [&](long nb, int axis) {
+        const int b = frag[nb];
+        if (!b || b == a) return;
+        const unsigned long long lo = (unsigned long long)(a < b ? a : b), hi = (unsigned long long)(a < b ? b : a);
+        int bin = (int)__fmul_rn(affs[(long)axis * N + u], 255.0f);              // (int)(affinity * (Bins - 1)), float32
+        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+        rec[nrec++] = (lo << 36) | (hi << 8) | (unsigned long long)bin;
+      };
+      if (u >= YX) emit(u - YX, 0);
+      if (y > 0) emit(u - X, 1);
+      if (x > 0) emit(u - 1, 2);
+    }
+  }
+  // one reservation per workgroup (the order of the records is irrelevant: the caller sorts them)
+  __shared__ int cnt[256]; __shared__ unsigned long long base;
+  cnt[threadIdx.x] = nrec; __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) { const int t = (int)threadIdx.x >= o ? cnt[threadIdx.x - o] : 0; __syncthreads(); cnt[threadIdx.x] += t; __syncthreads(); }
+  if (threadIdx.x == 255) base = cnt[255] ? atomicAdd(cursor, (unsigned long long)cnt[255]) : 0ull;
+  __syncthreads();
+  unsigned long long slot = base + (unsigned long long)(cnt[threadIdx.x] - nrec);
+  for (int k = 0; k < nrec; ++k, ++slot) if (slot < cap) keys[slot] = rec[k];
 }
 extern "C" int rg_ws_rag_count(const int32_t* frag, const int32_t* shape, uint64_t* count_dev, rg_stream s) {
   if (!frag || !shape || !count_dev) RG_FAIL(RG_ERR_BAD_SHAPE, "ws_rag_count: null argument");
