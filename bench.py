@@ -515,7 +515,7 @@ def main_config5(a, rank, local, world, dev):
         m = torch.tensor([nseg], device=dev, dtype=torch.int64)
         torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX)   # labels are global ranks of first voxels: the largest one is the count
         nseg = int(m.item())
-        backend = torch.distributed.get_backend()
+        backend = _backend_string()
         ranks_seen = torch.distributed.get_world_size()
         if rank != 0:
             torch.distributed.destroy_process_group()
@@ -684,6 +684,16 @@ def launch_ranks(a):
     return launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.rank_timeout)
 
 
+def _backend_string():
+    b = torch.distributed.get_backend()
+    if b == "nccl":     # (= RCCL on ROCm)
+        try:
+            b += " (RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()) + ")"
+        except Exception:
+            b += " (RCCL)"
+    return b
+
+
 def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf16", identity=0.0):
     """Time `steps` train steps of `workload` ('unet' | 'cyclegan') after `warmup` untimed ones: barrier + synchronize on both
     sides, MAX over ranks.  Returns the result dict (rank 0) or None."""
@@ -733,8 +743,7 @@ def run_train(a, workload, size, steps, warmup, rank, world, dev, precision="bf1
     prof = ops.profile_stop()
     waits = sync.wait_ms() if world > 1 else []   # per GradSync call: what the compute stream waited for the gradient exchange (not hidden by backward)
     comm = dict(ranks_seen=torch.distributed.get_world_size() if world > 1 else 1,
-                backend=(torch.distributed.get_backend() + (" (RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()) + ")"
-                                                           if torch.distributed.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
+                backend=_backend_string() if world > 1 else "none (single process)",
                 gradsync_algo=sync.algo, gradsync_calls_per_step=round(len(waits) / max(1, steps), 2),
                 allreduce_wait_ms_per_step=round(sum(waits) / max(1, steps), 3) if waits else 0.0,
                 allreduce_wait_ms_max_step=round(max(waits), 3) if waits else 0.0,

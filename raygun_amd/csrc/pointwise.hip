@@ -397,6 +397,8 @@ __global__ void act_bwd_bias_kernel(CL5 gy, CL5 y, CL5 g, float* partial, int ac
 // 16-byte pieces, piece i = (voxel i / S8, channel group i % S8), S8 = voxel stride / 8.  A thread's stride through the array is a
 // multiple of S8: its channel group never changes (no per-piece division), pieces of pad groups (>= G8) are skipped by the
 // threads that own them, and four pieces are in flight per thread.  partial[blockIdx.x][lanes] as in the general kernel.
+// ACT: RG_ACT_RELU compiled in (the U-Net's layers: the run-time switch of act_bwd_from_y costs a scalar branch per ELEMENT), -1 = the run-time switch
+template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_bias_dense_kernel(const bf16_t* gy, const bf16_t* y, bf16_t* g, float* partial, long npieces, int S8,
                                                                 int G8, int lanes, int act, float slope, int has_y, long step) {
   __shared__ float red[256 * 8];
@@ -419,7 +421,8 @@ __global__ __launch_bounds__(256) void act_bwd_bias_dense_kernel(const bf16_t* g
         if (has_y) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float gv = bf2f((bf16_t)a[u][k]) * act_bwd_from_y(bf2f((bf16_t)yy[u][k]), act, slope);
+            const float yv = bf2f((bf16_t)yy[u][k]);
+            const float gv = ACT == RG_ACT_RELU ? (yv > 0.f ? bf2f((bf16_t)a[u][k]) : 0.f) : bf2f((bf16_t)a[u][k]) * act_bwd_from_y(yv, act, slope);
             const bf16_t r = f2bf(gv); o[k] = (short)r; sum[k] += bf2f(r);
           }
         } else {
@@ -508,8 +511,12 @@ extern "C" int rg_act_bwd_bias(const rg_tensor* gy, const rg_tensor* y, const rg
       step = blocks * 256;
       if (partial && blocks < nblk && hipMemsetAsync(partial + blocks * GY.lanes, 0, (size_t)(nblk - blocks) * GY.lanes * 4, (hipStream_t)s) != hipSuccess)
         RG_FAIL(RG_ERR_HIP, "act_bwd: memset failed");
-      hipLaunchKernelGGL(act_bwd_bias_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)GY.p, has_y ? (const bf16_t*)Y.p : nullptr,
-                         has_g ? G.p : nullptr, partial, npieces, S8, G8, GY.lanes, act, slope, has_y, step);
+      if (has_y && act == RG_ACT_RELU)
+        hipLaunchKernelGGL(act_bwd_bias_dense_kernel<RG_ACT_RELU>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)GY.p, (const bf16_t*)Y.p,
+                           has_g ? G.p : nullptr, partial, npieces, S8, G8, GY.lanes, act, slope, has_y, step);
+      else
+        hipLaunchKernelGGL(act_bwd_bias_dense_kernel<-1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)GY.p, has_y ? (const bf16_t*)Y.p : nullptr,
+                           has_g ? G.p : nullptr, partial, npieces, S8, G8, GY.lanes, act, slope, has_y, step);
       RG_CHECK_LAUNCH();
       if (db) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(GY.C), dim3(256), 0, (hipStream_t)s, partial, db, nblk, GY.lanes, GY.C);

@@ -138,11 +138,26 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 d._combiner = kind(d, [roi(b) for b in mine], [roi(b) for b in range(len(blocks)) if b not in my_set], **kw)
                 combiners.append(d)
 
-    def fetch(bi):  # host side of one block: slice (or chunk reads + decompression), contiguous, pinned
+    AHEAD = 3                  # blocks the reader thread runs ahead of the GPU
+    pinned = []                # AHEAD + 1 reusable pinned staging buffers (a fresh pin_memory() per block costs a page-locking system call of milliseconds)
+    uploaded = {}              # staging buffer -> event recorded behind its asynchronous upload: the reader waits for it before it overwrites the buffer
+
+    def fetch(bi, slot):  # host side of one block: slice (or chunk reads + decompression), contiguous, into a pinned staging buffer
         wz, wy, wx = blocks[bi]
         rz, ry, rx = wz - context[0], wy - context[1], wx - context[2]
         a = np.ascontiguousarray(reader_src[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]])
-        return torch.from_numpy(a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))).pin_memory()
+        if not a.dtype.isnative:
+            a = a.astype(a.dtype.newbyteorder("="))
+        t = torch.from_numpy(a)
+        while len(pinned) <= slot:
+            pinned.append(None)
+        if pinned[slot] is None or pinned[slot].shape != t.shape or pinned[slot].dtype != t.dtype:
+            pinned[slot] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        ev = uploaded.pop(pinned[slot].data_ptr(), None)
+        if ev is not None:
+            ev.synchronize()
+        pinned[slot].copy_(t)
+        return pinned[slot]
 
     n_done = 0
     state = dict(drain=None, destinations=destinations)
@@ -150,7 +165,8 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
     if not resident and len(mine):
         from concurrent.futures import ThreadPoolExecutor
         reader = ThreadPoolExecutor(max_workers=1)
-        ahead = reader.submit(fetch, mine[0])
+        import collections
+        ahead = collections.deque(reader.submit(fetch, mine[j], j % (AHEAD + 1)) for j in range(min(AHEAD, len(mine))))
 
     def run_block(bi, host):
         """Forward + crop + convert + hand-over of one block; returns a 0-d device bool: every output value finite."""
@@ -160,6 +176,7 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
             blk = source[rz:rz + read[0], ry:ry + read[1], rx:rx + read[2]][None, None]
         else:
             blk = host.to(dev, non_blocking=True)[None, None]
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev)); uploaded[host.data_ptr()] = ev
         if blk.dtype not in (torch.uint8,):
             blk = blk.float()
         x = ops.to_cl(blk, scale, shift)  # normalisation fused into the NCDHW -> NDHWC bf16 conversion
@@ -173,9 +190,15 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 c = o.shape[1]
                 dt = np.float32 if out_dtypes is None else out_dtypes[i]
                 shp = ((c,) if c > 1 else ()) + tuple(source.shape)
-                dd.append(torch.zeros(shp, dtype=_TORCH_DT[np.dtype(dt)], device=dev) if resident else np.zeros(shp, dtype=dt))
-            state["destinations"] = dd
+                dd.append((shp, np.dtype(dt)))
+            # destinations this call allocates itself live in HBM while the blocks run — also for a host-resident source, as long as they fit a budget: one
+            # contiguous download at the end instead of a strided host scatter per block (19-24 blocks/s with numpy destinations; the zarr flow made the same move)
+            total = sum(int(np.prod(shp)) * dt.itemsize for shp, dt in dd)
+            on_dev = resident or (total <= int(os.environ.get("RAYGUN_AMD_PREDICT_HBM_BUDGET", str(96 << 30))) and all(dt in _TORCH_DT for _, dt in dd))
+            state["destinations"] = [torch.zeros(shp, dtype=_TORCH_DT[dt], device=dev) if on_dev else np.zeros(shp, dtype=dt) for shp, dt in dd]
+            state["download"] = on_dev and not resident
         dests = state["destinations"]
+        dres = all(torch.is_tensor(d) and d.is_cuda for d in dests)
         out_dt = {id(d): (np.dtype(str(d.dtype).replace("torch.", "")) if torch.is_tensor(d) else d.dtype) for d in dests}
         finite = None
         flag = None
@@ -192,7 +215,7 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 if flag is None:
                     flag = torch.zeros(1, dtype=torch.float32, device=dev)
                 roi = (Ellipsis, slice(wz, wz + write[0]), slice(wy, wy + write[1]), slice(wx, wx + write[2]))
-                if resident:
+                if dres:
                     tgt = dest[roi]
                 else:
                     tgt = torch.empty(((o.shape[1],) if dest.ndim == 4 else ()) + tuple(write), dtype=_TORCH_DT[odt], device=dev)
@@ -201,7 +224,7 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                     raise ValueError(f"destination {tuple(dest.shape)} does not match the network's {o.shape[1]} output channels")
                 isint = odt == np.dtype(np.uint8)
                 ops.store_block(o, view[None], 255.0 if isint else 1.0, 0.0, 255.0, flag)
-                if not resident:
+                if not dres:
                     comb = getattr(dest, "_combiner", None)
                     if comb is not None and hasattr(comb, "dev"):       # chunk buffers in HBM: GPU copies now, one contiguous download per finished chunk (blockio.py)
                         lead = () if tgt.dim() == 3 else (0,)
@@ -220,7 +243,7 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 o = o[..., off[0]:off[0] + write[0], off[1]:off[1] + write[1], off[2]:off[2] + write[2]]
             f = torch.isfinite(o).all()
             finite = f if finite is None else finite & f
-            if resident:
+            if dres:
                 dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)], True)
             elif np.dtype(out_dt[id(dest)]) not in _TORCH_DT:  # e.g. uint16: no torch twin, convert on the host
                 dest[..., wz:wz + write[0], wy:wy + write[1], wx:wx + write[2]] = _to_destination(o if dest.ndim == 4 else o[0], out_dt[id(dest)])
@@ -239,8 +262,9 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
         for k, bi in enumerate(mine):
             host = None
             if not resident:
-                host = ahead.result()
-                ahead = reader.submit(fetch, mine[k + 1]) if k + 1 < len(mine) else None
+                host = ahead.popleft().result()
+                if k + AHEAD < len(mine):      # (its staging slot was last used by block k - 1, whose upload was enqueued before block k - 1's forward)
+                    ahead.append(reader.submit(fetch, mine[k + AHEAD], (k + AHEAD) % (AHEAD + 1)))
             flags.append(run_block(bi, host))
             n_done += 1
         # IEEE-half storage overflows at 65504 where fp32 (the reference) and bf16 stay finite, and integer destinations would
@@ -253,7 +277,7 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
             if ops.storage_dtype() != torch.bfloat16:
                 log.warning("non-finite output in %d of %d block(s) with f16 storage (half's range is 65504): re-running them with bf16 storage", len(bad), len(mine))
                 with ops.precision("bf16"):
-                    again = [run_block(bi, None if resident else fetch(bi)) for bi in bad]
+                    again = [run_block(bi, None if resident else fetch(bi, AHEAD)) for bi in bad]
                 FALLBACK_BLOCKS.extend(bad)
                 bad = [bi for bi, ok in zip(bad, torch.stack(again).tolist()) if not ok]
             if bad:
@@ -291,6 +315,8 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
     if reader_src is not source:
         reader_src.close()
     destinations = state["destinations"]
+    if state.get("download") and destinations is not None:      # allocated in HBM for a host-side caller: hand back host arrays, as before
+        destinations = [d.cpu().numpy() for d in destinations]
     return destinations, n_done
 
 
