@@ -191,10 +191,11 @@ def _predict_volume(model, source, input_shape, output_shape, read_size, crop, n
                 dt = np.float32 if out_dtypes is None else out_dtypes[i]
                 shp = ((c,) if c > 1 else ()) + tuple(source.shape)
                 dd.append((shp, np.dtype(dt)))
-            # destinations this call allocates itself live in HBM while the blocks run — also for a host-resident source, as long as they fit a budget: one
-            # contiguous download at the end instead of a strided host scatter per block (19-24 blocks/s with numpy destinations; the zarr flow made the same move)
+            # OPT-IN (RAYGUN_AMD_PREDICT_HBM_BUDGET = bytes): destinations this call allocates itself live in HBM while the blocks run also for a host-resident
+            # source, one download at the end.  Measured (404^3, 20 + 10 channels): 14.6 / 20.1 blocks/s (uint8 / float32) against 19.5 / 24.2 for the drain thread's
+            # per-block pinned downloads, which overlap the forward passes — a 2-8 GB pageable download at the end does not — so the drain thread stays the default
             total = sum(int(np.prod(shp)) * dt.itemsize for shp, dt in dd)
-            on_dev = resident or (total <= int(os.environ.get("RAYGUN_AMD_PREDICT_HBM_BUDGET", str(96 << 30))) and all(dt in _TORCH_DT for _, dt in dd))
+            on_dev = resident or (total <= int(os.environ.get("RAYGUN_AMD_PREDICT_HBM_BUDGET", "0")) and all(dt in _TORCH_DT for _, dt in dd))
             state["destinations"] = [torch.zeros(shp, dtype=_TORCH_DT[dt], device=dev) if on_dev else np.zeros(shp, dtype=dt) for shp, dt in dd]
             state["download"] = on_dev and not resident
         dests = state["destinations"]

@@ -30,6 +30,10 @@ def run(B, m, k, n, reps=5, check=False):
     for opt in (1, -1):
         t = min(r[0] for r in res[opt]); tm = sorted(r[0] for r in res[opt])[1]
         print(f"B={B:3d} m={m:5d} k={k:6d} n={n:5d} opt={opt:2d}: min {t:.3f} ms median {tm:.3f} ms  {2.0*B*m*k*n/t/1e9:7.0f} TF/s  {res[opt][0][1]}", flush=True)
+if len(sys.argv) > 2 and sys.argv[1] == "shape":      # python3 tools/bench_gemm.py shape B,m,k,n [B,m,k,n ...]
+    for a in sys.argv[2:]:
+        run(*[int(v) for v in a.split(",")])
+    sys.exit(0)
 chk = len(sys.argv) > 1 and sys.argv[1] == "check"
 if chk:
     for cfg in [(2, 300, 200, 288), (3, 700, 2592, 576), (1, 257, 64, 144), (2, 1000, 448, 432)]:
