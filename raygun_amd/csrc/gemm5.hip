@@ -296,7 +296,8 @@ static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size
   const long tiles = tiles_m * tiles_n * nbatch;
   if (opt == 1) { pl.fn = fn; return pl; }
   const double fill_n = (double)wrows / (double)(tiles_n * bn);
-  if (fill_n < (opt == 2 ? 0.70 : 0.88) || kunits < 8) return pl;
+  // (batched GEMMs — the Winograd products — take a 75 %-full column tiling too: 64 x [1331 x 2592] x [2592 x 432] measured 0.295 ms here against 0.328 on igemm4)
+  if (fill_n < ((opt == 2 || nbatch > 1) ? 0.70 : 0.88) || kunits < 8) return pl;
   auto round_fill = [](long t) { const double r = (double)t / 256.0; return r / (double)(long)(r + 0.999999); };
   if (tiles >= 150 && round_fill(tiles) >= 0.70) { pl.fn = fn; return pl; }
   if (nbatch == 1 && tiles < 150 && kunits >= 32 && (cout_lanes & 3) == 0) {   // split K: whole rounds of one workgroup per CU

@@ -311,6 +311,7 @@ __global__ void pad_fwd_kernel(CL5 x, CL5 y, int pd, int ph, int pw, int mode) {
     bf16x8 v = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     bool ok = true;
     if (mode == 1) { sd = reflect_idx(sd, x.D); sh = reflect_idx(sh, x.H); sw = reflect_idx(sw, x.W); }
+    else if (mode == 2) { sd = min(max(sd, 0), x.D - 1); sh = min(max(sh, 0), x.H - 1); sw = min(max(sw, 0), x.W - 1); }   // replicate: clamp to the border voxel
     else ok = (unsigned)sd < (unsigned)x.D && (unsigned)sh < (unsigned)x.H && (unsigned)sw < (unsigned)x.W;
     if (ok) v = *(const bf16x8*)(x.p + n * x.sn + (long)sd * x.sd + (long)sh * x.sh + (long)sw * x.sw + grp * 8);
     *(bf16x8*)(y.p + n * y.sn + d * y.sd + h * y.sh + w * y.sw + grp * 8) = v;
@@ -322,15 +323,31 @@ __device__ __forceinline__ int pad_sources(int i, int n, int p, int mode, int ou
   if (mode == 1) { if (i >= 1 && i <= p) out[k++] = p - i; if (i >= n - 1 - p && i <= n - 2) out[k++] = 2 * (n - 1) - i + p; }
   return k;
 }
+// replicate: padded index range [lo, hi] that maps onto source index i (the border voxels collect their whole pad strip)
+__device__ __forceinline__ void pad_range_replicate(int i, int n, int p, int& lo, int& hi) { lo = i == 0 ? 0 : i + p; hi = i == n - 1 ? n - 1 + 2 * p : i + p; }
 __global__ void pad_bwd_kernel(CL5 gy, CL5 gx, int pd, int ph, int pw, int mode) {
   const int G8 = gx.lanes / 8;
   const long total = (long)gx.N * gx.D * gx.H * gx.W * G8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int grp = (int)(i % G8); long t = i / G8;
     const int w = (int)(t % gx.W); t /= gx.W; const int h = (int)(t % gx.H); t /= gx.H; const int d = (int)(t % gx.D); const int n = (int)(t / gx.D);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (mode == 2) {
+      int d0, d1, h0, h1, w0, w1;
+      pad_range_replicate(d, gx.D, pd, d0, d1); pad_range_replicate(h, gx.H, ph, h0, h1); pad_range_replicate(w, gx.W, pw, w0, w1);
+      for (int a = d0; a <= d1; ++a) for (int b = h0; b <= h1; ++b) for (int c = w0; c <= w1; ++c) {
+        const bf16x8 v = *(const bf16x8*)(gy.p + n * gy.sn + (long)a * gy.sd + (long)b * gy.sh + (long)c * gy.sw + grp * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += bf2f((bf16_t)v[k]);
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (short)f2bf(acc[k]);
+      *(bf16x8*)(gx.p + n * gx.sn + d * gx.sd + h * gx.sh + w * gx.sw + grp * 8) = o;
+      continue;
+    }
     int ds[3], hs[3], ws[3];
     const int nd = pad_sources(d, gx.D, pd, mode, ds), nh = pad_sources(h, gx.H, ph, mode, hs), nw = pad_sources(w, gx.W, pw, mode, ws);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int a = 0; a < nd; ++a) for (int b = 0; b < nh; ++b) for (int c = 0; c < nw; ++c) {
       const bf16x8 v = *(const bf16x8*)(gy.p + n * gy.sn + (long)ds[a] * gy.sd + (long)hs[b] * gy.sh + (long)ws[c] * gy.sw + grp * 8);
 #pragma unroll
@@ -346,7 +363,7 @@ static int pad_check(const CL5& X, const CL5& Y, const int32_t pad[3], int mode,
   if (Y.N != X.N || Y.C != X.C || Y.D != X.D + 2 * pad[0] || Y.H != X.H + 2 * pad[1] || Y.W != X.W + 2 * pad[2]) RG_FAIL(RG_ERR_BAD_SHAPE, "%s: padded shape mismatch", what);
   if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0) RG_FAIL(RG_ERR_BAD_SHAPE, "%s: negative pad", what);
   if (mode == 1 && (pad[0] >= X.D || pad[1] >= X.H || pad[2] >= X.W)) RG_FAIL(RG_ERR_BAD_SHAPE, "%s: reflect pad must be smaller than the input", what);
-  if (mode != 0 && mode != 1) RG_FAIL(RG_ERR_UNSUPPORTED, "%s: mode %d", what, mode);
+  if (mode != 0 && mode != 1 && mode != 2) RG_FAIL(RG_ERR_UNSUPPORTED, "%s: mode %d (0 zeros, 1 reflect, 2 replicate)", what, mode);
   return RG_OK;
 }
 extern "C" int rg_pad3d_fwd(const rg_tensor* x, const rg_tensor* y, const int32_t pad[3], int mode, rg_stream s) {

@@ -123,14 +123,14 @@ class Conv3d(nn.Conv3d):
     def _check(self):
         if self.groups != 1 or any(d != 1 for d in self.dilation):
             raise RuntimeError("raygun_amd.Conv3d: groups/dilation != 1 are not built (use torch.nn.Conv3d)")
-        if self.padding_mode not in ("zeros", "reflect"):
+        if self.padding_mode not in ("zeros", "reflect", "replicate"):
             raise RuntimeError(f"raygun_amd.Conv3d: padding_mode {self.padding_mode!r} is not built")
 
     def run(self, x, act="none", slope=0.0):
         self._check()
         pads = self._pads()
-        if self.padding_mode == "reflect" and any(pads):
-            x = ops.pad3d(x, pads, "reflect")
+        if self.padding_mode in ("reflect", "replicate") and any(pads):
+            x = ops.pad3d(x, pads, self.padding_mode)
             pads = (0, 0, 0)
         return ops.conv3d(x, self.weight, self.bias, self.stride, pads, act, slope)
 
@@ -240,6 +240,13 @@ class ReflectionPad3d(nn.ReflectionPad3d):
         return ops.pad3d(x, _symmetric(self.padding, "ReflectionPad3d"), "reflect")
 
 
+class ReplicationPad3d(nn.ReplicationPad3d):
+    """padding_type="replicate" of the generators (ResNet.py:272-273, 394-395): the pad kernel's clamp mode."""
+    @scoped
+    def forward(self, x):
+        return ops.pad3d(x, _symmetric(self.padding, "ReplicationPad3d"), "replicate")
+
+
 class MaxPool3d(nn.MaxPool3d):
     @scoped
     def forward(self, x):
@@ -278,12 +285,12 @@ class Conv2d(nn.Conv2d):
     def run(self, x, act="none", slope=0.0):
         if self.groups != 1 or any(d != 1 for d in self.dilation):
             raise RuntimeError("raygun_amd.Conv2d: groups/dilation != 1 are not built (use torch.nn.Conv2d)")
-        if self.padding_mode not in ("zeros", "reflect"):
+        if self.padding_mode not in ("zeros", "reflect", "replicate"):
             raise RuntimeError(f"raygun_amd.Conv2d: padding_mode {self.padding_mode!r} is not built")
         x = ops.enter(x)
         pads = self._pads()
-        if self.padding_mode == "reflect" and any(pads):
-            x = ops.pad3d(x, (0,) + pads, "reflect")
+        if self.padding_mode in ("reflect", "replicate") and any(pads):
+            x = ops.pad3d(x, (0,) + pads, self.padding_mode)
             pads = (0, 0)
         return ops.conv3d(x, self.weight.unsqueeze(2), self.bias, (1,) + tuple(self.stride), (0,) + pads, act, slope)
 
@@ -343,6 +350,16 @@ class ReflectionPad2d(nn.ReflectionPad2d):
         return ops.pad3d(ops.enter(x), (0, p[2], p[0]), "reflect")
 
 
+class ReplicationPad2d(nn.ReplicationPad2d):
+    @scoped
+    def forward(self, x):
+        p = self.padding
+        p = (p,) * 4 if isinstance(p, int) else tuple(p)
+        if not (p[0] == p[1] and p[2] == p[3]):
+            raise RuntimeError(f"raygun_amd.ReplicationPad2d: only symmetric padding is supported, got {p}")
+        return ops.pad3d(ops.enter(x), (0, p[2], p[0]), "replicate")
+
+
 class MaxPool2d(nn.MaxPool2d):
     @scoped
     def forward(self, x):
@@ -356,7 +373,7 @@ _HIP_LAYER = {"Conv3d": Conv3d, "ConvTranspose3d": ConvTranspose3d, "InstanceNor
               "ReflectionPad3d": ReflectionPad3d, "MaxPool3d": MaxPool3d, "ReLU": ReLU, "LeakyReLU": LeakyReLU,
               "Sigmoid": Sigmoid, "Tanh": Tanh, "Conv2d": Conv2d, "ConvTranspose2d": ConvTranspose2d,
               "InstanceNorm2d": InstanceNorm2d, "ReflectionPad2d": ReflectionPad2d, "MaxPool2d": MaxPool2d,
-              "BatchNorm3d": BatchNorm3d, "BatchNorm2d": BatchNorm2d}
+              "BatchNorm3d": BatchNorm3d, "BatchNorm2d": BatchNorm2d, "ReplicationPad3d": ReplicationPad3d, "ReplicationPad2d": ReplicationPad2d}
 _CONVS = (Conv3d, ConvTranspose3d, Conv2d, ConvTranspose2d)
 _NORMS = (InstanceNorm3d, InstanceNorm2d, BatchNorm3d, BatchNorm2d)
 
@@ -422,7 +439,7 @@ class FusedSequential(nn.Sequential):
             elif act_of(m) is not None and not isinstance(m, (ReLU, LeakyReLU, Sigmoid, Tanh)):
                 a = act_of(m)  # a plain torch.nn activation instance handed in by the user
                 x = ops.activation(x, a[0], a[1]); i += 1
-            elif isinstance(m, (ReflectionPad3d, MaxPool3d, ReflectionPad2d, MaxPool2d, ReLU, LeakyReLU, Sigmoid, Tanh, FusedSequential)) or \
+            elif isinstance(m, (ReflectionPad3d, ReplicationPad3d, MaxPool3d, ReflectionPad2d, ReplicationPad2d, MaxPool2d, ReLU, LeakyReLU, Sigmoid, Tanh, FusedSequential)) or \
                     getattr(m, "_raygun_amd", False):
                 x = m(x); i += 1
             elif isinstance(m, nn.Identity):

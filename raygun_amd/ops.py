@@ -1327,7 +1327,7 @@ class _Pad3d(Function):
 
 
 def pad3d(x, pad, mode="reflect"):
-    return _Pad3d.apply(x, _triple(pad), {"zeros": 0, "reflect": 1}[mode])
+    return _Pad3d.apply(x, _triple(pad), {"zeros": 0, "reflect": 1, "replicate": 2}[mode])
 
 
 class _Add(Function):

@@ -15,7 +15,7 @@ def _padder(padding_type, width, nd=3):
     if pt in ("reflect", "same"):
         return [hipnn.layers(nd)[3](width)], 0
     if pt == "replicate":
-        return [getattr(nn, f"ReplicationPad{nd}d")(width)], 0  # torch op (not on the benchmark path)
+        return [{3: hipnn.ReplicationPad3d, 2: hipnn.ReplicationPad2d}[nd](width)], 0
     if pt == "zeros":
         return [], width
     if pt == "valid":

@@ -190,12 +190,12 @@ def test_instance_norm_residual():
     check(errs)
 
 
-@pytest.mark.parametrize("mode", ["reflect", "zeros"])
+@pytest.mark.parametrize("mode", ["reflect", "zeros", "replicate"])
 @pytest.mark.parametrize("pad", [1, 3])
 def test_pad3d(mode, pad):
     from raygun_amd import ops
     x = rnd((2, 5, 6, 7, 8), 61)
-    ref = (lambda t: F.pad(t, (pad,) * 6, mode="reflect")) if mode == "reflect" else (lambda t: F.pad(t, (pad,) * 6))
+    ref = (lambda t: F.pad(t, (pad,) * 6, mode=mode)) if mode != "zeros" else (lambda t: F.pad(t, (pad,) * 6))
     errs = run_pair(lambda t: ops.pad3d(t, pad, mode), ref, [x], [])
     check(errs, 4e-3)
 
