@@ -19,7 +19,7 @@ void rg_set_kernel_name(const char* fmt, ...);  // name of the dominant kernel o
 void rg_prof_mark(hipStream_t st);              // HIP event before / after the dominant kernel when rg_profile_enable(1)
 // Diagnostic switches (rg_set_option / the RG_* environment variables read ONCE when the library is loaded — never in a launch path).
 // 0 = production default everywhere.
-enum { RG_OPT_FM = 0, RG_OPT_NO_HALO, RG_OPT_NO_THIN, RG_OPT_NO_THIN3, RG_OPT_NO_WLINES, RG_OPT_NO_KWP, RG_OPT_DEBUG_BOUNDS, RG_OPT_GEMM5, RG_OPT_NO_WGEMM, RG_OPT_MWS_WGS, RG_OPT_MWS_WMUL, RG_OPT_COUNT };
+enum { RG_OPT_FM = 0, RG_OPT_NO_HALO, RG_OPT_NO_THIN, RG_OPT_NO_THIN3, RG_OPT_NO_WLINES, RG_OPT_NO_KWP, RG_OPT_DEBUG_BOUNDS, RG_OPT_GEMM5, RG_OPT_NO_WGEMM, RG_OPT_MWS_WGS, RG_OPT_MWS_WMUL, RG_OPT_SK, RG_OPT_COUNT };
 int rg_opt(int which);
 // "once per device" latch for hipFuncSetAttribute (a function attribute belongs to the device that was current when it was set):
 // `fn` runs exactly once per (latch, current device), under the latch lock: a second host thread (autograd's) launching the same

@@ -18,6 +18,7 @@ bool rg_igemm3_ok(const CL5& X, const rg_conv_params* p);
 bool rg_igemm4_ok(const CL5& X, const rg_conv_params* p);
 int rg_igemm4_tile_n(int cout);
 bool rg_igemm5_wanted(const CL5& X, const CL5& Y, const rg_conv_params* p, size_t ws_bytes);   // gemm5.hip
+size_t rg_igemm5_sk_bytes(const CL5& X, const CL5& Y, const rg_conv_params* p);
 int rg_launch_igemm4(const CL5& X, const CL5& Y, const void* w_packed, const float* bias, const rg_conv_params* p, hipStream_t st, int flat,
                      void* workspace, size_t ws_bytes);
 __device__ __attribute__((aligned(128))) unsigned short rg_zero_page[64];  // zero-initialised with the code object
@@ -60,8 +61,10 @@ extern "C" int64_t rg_conv3d_igemm_workspace_bytes(const rg_tensor* x, const rg_
   if (rg_as_cl5(x, &X, "conv.x") || rg_as_cl5(y, &Y, "conv.y") || !p) return -1;
   const long M = (long)X.N * p->R[0] * p->R[1] * p->R[2];
   const long tiles64 = ((M + 63) / 64) * ((Y.lanes + 143) / 144);   // the smallest tile the engine uses
-  if (tiles64 > 1024 || Y.lanes < 64) return 0;                      // cannot be at most half a round of any tile shape / thin kernels
-  return (int64_t)8 * M * Y.lanes * 4;
+  const int64_t sk = rg_conv3d_kalign(X.C, p->cout) == 64 ? (int64_t)rg_igemm5_sk_bytes(X, Y, p) : 0;   // stream-K partial slots (gemm5.hip)
+  if (tiles64 > 1024 || Y.lanes < 64) return sk;                     // cannot be at most half a round of any tile shape / thin kernels
+  const int64_t split = (int64_t)8 * M * Y.lanes * 4;
+  return split > sk ? split : sk;
 }
 extern "C" int rg_conv3d_igemm2(const rg_tensor* x, const void* w_packed, const float* bias, const rg_tensor* y,
                                 const rg_conv_params* p, void* workspace, size_t ws_bytes, rg_stream s) {

@@ -447,6 +447,7 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   Igemm4Args a;
   a.d2s_c = 0;
   a.wld = 0; a.nbatch1 = 0; a.wbatch2 = 0; a.raw = nullptr; a.raw_ld = 0; a.raw_batch = 0;
+  a.sk_grid = 0; a.sk_part = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0;
   a.nbatch = bt ? bt->n : 1; a.xbatch = bt ? bt->xs : 0; a.wbatch = bt ? bt->ws : 0; a.ybatch = bt ? bt->ys : 0;
   a.x = X.p; a.w = (const bf16_t*)w_packed; a.bias = bias; a.y = Y.p;
   a.N = X.N; a.ID = X.D; a.IH = X.H; a.IW = X.W;

@@ -24,6 +24,8 @@
 // C[b][m][n] = sum_k A[b][m][k] * W[b][n][k]  (+ bias[n], activation), 16-bit storage type of this build, fp32 accumulation.
 #include "igemm_args.h"
 #include <utility>
+#include <atomic>
+#include <mutex>
 
 typedef int g5_i32x4 __attribute__((ext_vector_type(4)));
 
@@ -56,31 +58,60 @@ __device__ __forceinline__ void g5for(F&& f) { g5_impl(f, std::make_integer_sequ
 // (zeros).  rg_gemm_batched's problems are the 1x1x1-tap case with a batch index in the grid.
 // FN = 16-column fragments per wave: 9 (144-column halves, 288-column tiles: the U-Net's 432 / 2592 / 3456-channel layers) or 8 (128-column
 // halves, 256-column tiles: the CycleGAN's 256-channel ResNet blocks).
-template <bool CHECK, int FN, bool RAW = false>   // RAW: the weight-gradient form (raw fp32 tiles into the caller's matrix; its own instantiation = its own name in profiles)
+template <bool CHECK, int FN, bool RAW = false, bool SK = false>   // RAW: the weight-gradient form (raw fp32 tiles into the caller's matrix; its own instantiation = its own name in profiles)
 __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   constexpr int G5_BN = 2 * FN * 16, NB = (G5_BN + 63) / 64;   // columns per tile, B DMA instructions per thread and K-tile
   extern __shared__ __attribute__((aligned(128))) unsigned char g5_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;     // row group (64 rows), column group (144 columns); column group = stagger group
-  const int nwg = a.tiles_m * a.tiles_n * a.ksplit * a.nbatch;
+  const int nwg = SK ? a.sk_grid : a.tiles_m * a.tiles_n * a.ksplit * a.nbatch;
   int bid = blockIdx.x;
   { const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8; bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
-  const int batch = bid / (a.tiles_m * a.tiles_n * a.ksplit); bid -= batch * (a.tiles_m * a.tiles_n * a.ksplit);
-  const int split = bid / (a.tiles_m * a.tiles_n); bid -= split * (a.tiles_m * a.tiles_n);
-  const int tile_n = bid / a.tiles_m, tile_m = bid - tile_n * a.tiles_m;
+  const int wg = bid;
+  const int ntaps = a.TD * a.TH * a.TW, nchunk = a.cink >> 6;
+  const int kunits = nchunk * ntaps;
+  // SK: this workgroup's run [u, u_end) of the flattened (tile, K-tile) space, one pass of the loop below per tile it touches.  Order: the piece of
+  // the LAST tile first when the run ends inside that tile (a head piece: K-tiles 0 .., handed over as a partial), then the rest front to back (the
+  // tail of the first tile — which this workgroup finishes — and whole tiles).  Head pieces start at K-tile 0 at time 0 everywhere and tail pieces
+  // end together, so the workgroups of an XCD walk the weights in (two) lockstep fronts and B stays an L2 hit; natural order spreads the 32 of them
+  // over 32 different K-tiles (measured 127 us against 95 for the ResNet-block forward with all hand-overs disabled).
+  const long sk_units = SK ? (long)a.tiles_m * a.tiles_n * a.nbatch * kunits : 0;
+  long u = SK ? sk_units * wg / nwg : 0;
+  const long u_end = SK ? sk_units * (wg + 1) / nwg : 0;
+  if (SK && u >= u_end) return;
+  long sk_stop = u_end;                      // end of the front-to-back part
+  bool head_first = false;
+  if constexpr (SK) {
+    const long ls = ((u_end - 1) / kunits) * kunits;
+    if (ls > u && u_end < ls + kunits) { head_first = true; sk_stop = ls; }
+  }
+  for (;;) {
+  int batch, split, tile_n, tile_m, ku0, ku1;
+  long sk_tile = 0, sk_su = 0;
+  if constexpr (SK) {
+    long se;
+    if (head_first) { sk_su = sk_stop; se = u_end; }
+    else { sk_su = u; se = (u / kunits + 1) * kunits; if (se > sk_stop) se = sk_stop; }
+    sk_tile = sk_su / kunits; ku0 = (int)(sk_su - sk_tile * kunits); ku1 = ku0 + (int)(se - sk_su);
+    int tb = (int)sk_tile;
+    batch = tb / (a.tiles_m * a.tiles_n); tb -= batch * (a.tiles_m * a.tiles_n);
+    tile_n = tb / a.tiles_m; tile_m = tb - tile_n * a.tiles_m; split = 0;
+  } else {
+    batch = bid / (a.tiles_m * a.tiles_n * a.ksplit); bid -= batch * (a.tiles_m * a.tiles_n * a.ksplit);
+    split = bid / (a.tiles_m * a.tiles_n); bid -= split * (a.tiles_m * a.tiles_n);
+    tile_n = bid / a.tiles_m; tile_m = bid - tile_n * a.tiles_m;
+    // K range of this workgroup in K-tiles (tile = chunk * ntaps + tap): everything, or the split's share
+    const int kper = (kunits + a.ksplit - 1) / a.ksplit;
+    ku0 = split * kper; ku1 = ku0 + kper < kunits ? ku0 + kper : kunits;
+  }
+  const int nk = ku1 > ku0 ? ku1 - ku0 : 0;
   const long m0 = (long)tile_m * G5_BM;
   const int n0 = tile_n * G5_BN;
   const bf16_t* const xbase = a.x + batch * a.xbatch;
   const bf16_t* const wbase = a.nbatch1 ? a.w + (batch % a.nbatch1) * a.wbatch + (batch / a.nbatch1) * a.wbatch2 : a.w + batch * a.wbatch;
-  bf16_t* const ybase = a.y + batch * a.ybatch;
   const g5_i32x4 ra = g5_rsrc(xbase, a.xbytes), rw = g5_rsrc(wbase, a.wbytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)g5_lds;
-  const int ntaps = a.TD * a.TH * a.TW, nchunk = a.cink >> 6;
-  // K range of this workgroup in K-tiles (tile = chunk * ntaps + tap): everything, or the split's share
-  const int kunits = nchunk * ntaps, kper = (kunits + a.ksplit - 1) / a.ksplit;
-  const int ku0 = split * kper, ku1 = ku0 + kper < kunits ? ku0 + kper : kunits;
-  const int nk = ku1 > ku0 ? ku1 - ku0 : 0;
 
   // ---- DMA pieces of this thread: instruction i covers tile rows i*64 + wave*8 + (lane>>3); the lane fetches the piece that
   // belongs in ITS slot of the swizzled image
@@ -211,16 +242,20 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   if (!wn) __builtin_amdgcn_s_barrier();     // matches the trailing group's extra barrier
 
   // ---- epilogue: lane holds columns c .. c+3 of row (lane & 15) of every fragment
+  // (SK: the lane indices pass through an opaque move first, so that nothing of the epilogue's address arithmetic is loop-invariant — hoisted in front
+  // of the run loop it would stay live across the K loop and spill)
+  int efr = fr, efg = fg, etid = tid;
+  if constexpr (SK) asm volatile("" : "+v"(efr), "+v"(efg), "+v"(etid));
   if constexpr (RAW) {  // raw fp32 tile straight into the caller's matrix (the weight gradient: row = output channel, column = input channel of one tap)
     float* const obase = a.raw + batch * a.raw_batch;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wm * 64 + i * 16 + fr;
+      const long m = m0 + wm * 64 + i * 16 + efr;
       if (m >= a.M) continue;
       float* prow = obase + m * a.raw_ld;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
+        const int c = n0 + wn * (FN * 16) + j * 16 + efg * 4;
         if (c + 3 < a.cout) *(f32x4*)(prow + c) = acc[i][j];
         else {
 #pragma unroll
@@ -230,23 +265,68 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
     }
     return;
   }
-  if (a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the 16-bit store happen in the combine kernel
+  if (!SK && a.ksplit > 1) {   // split-K: raw fp32 sums; bias, activation and the 16-bit store happen in the combine kernel
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wm * 64 + i * 16 + fr;
+      const long m = m0 + wm * 64 + i * 16 + efr;
       if (m >= a.M) continue;
       float* prow = a.part + ((long)split * a.M + m) * a.cout_lanes;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
+        const int c = n0 + wn * (FN * 16) + j * 16 + efg * 4;
         if (c < a.cout_lanes) *(f32x4*)(prow + c) = acc[i][j];
       }
     }
     return;
   }
+  bool finish = true;
+  if constexpr (SK) {
+    // Partials and flags move with device-scope (sc1) accesses: written through to / read from the memory side of the per-XCD L2s, so no cache-wide
+    // write-back or invalidate is needed (the agent-scope fences that would make ordinary stores visible cost 35-50 us per launch: they flush and
+    // drop the whole L2 under the workgroups still computing)
+    constexpr long SLOT = 4L * FN * 512 * 4;   // floats per workgroup: accumulator (i, j) of thread t at ((i * FN + j) * 512 + t) * 4
+    if (ku1 != kunits) {
+      // the piece ends inside its tile: leave the sums for the workgroup that holds the tile's last K-tile
+      float* slot = a.sk_part + (long)wg * SLOT + etid * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + (i * FN + j) * 2048), "v"(acc[i][j]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have been acknowledged
+      __syncthreads();                                     // ... and everybody's
+      if (etid == 0) __hip_atomic_fetch_max(a.sk_flags + wg, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      finish = false;
+    } else if (ku0 != 0) {
+      // the tail of a tile others started: every workgroup below this one whose run reaches into the tile left ONE partial there, the piece it
+      // computes FIRST — before anything it might wait for itself, so this wait cannot deadlock whatever the dispatch order
+      const long tile_start = sk_tile * kunits;
+      long cov = sk_su;
+      for (int w2 = wg - 1; cov > tile_start && w2 >= 0; --w2) {
+        const long s2 = sk_units * w2 / nwg;
+        if (s2 == cov) continue;                           // (an empty run)
+        if (etid == 0) { while (__hip_atomic_load(a.sk_flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sk_epoch < 0) __builtin_amdgcn_s_sleep(4); }
+        __syncthreads();
+        const float* slot = a.sk_part + (long)w2 * SLOT + etid * 4;
+        // one accumulator row (FN loads in flight) at a time: the fragment registers are free here, more would spill
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v[FN];
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[j]) : "v"(slot + (i * FN + j) * 2048) : "memory");
+          if constexpr (FN == 9) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]) :: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+          for (int j = 0; j < FN; ++j) { acc[i][j][0] += v[j][0]; acc[i][j][1] += v[j][1]; acc[i][j][2] += v[j][2]; acc[i][j][3] += v[j][3]; }
+        }
+        cov = s2;
+      }
+    }
+  }
+  if (finish) {
+  bf16_t* const ybase = a.y + batch * a.ybatch;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m = m0 + wm * 64 + i * 16 + fr;
+    const long m = m0 + wm * 64 + i * 16 + efr;
     if (m >= a.M) continue;
     long t = m;
     const int rw_ = (int)(t % a.RW); t /= a.RW;
@@ -256,7 +336,7 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
                    (long)(rw_ * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int c = n0 + wn * (FN * 16) + j * 16 + fg * 4;
+      const int c = n0 + wn * (FN * 16) + j * 16 + efg * 4;
       if (c >= a.cout_lanes) continue;
       int cc = c; long yo = 0;
       if (a.d2s_c) {   // depth-to-space: column block q = c / C is parity (qd, qh, qw) of output voxel 2 * row + parity (the 4 columns share q: C % 16 == 0)
@@ -276,6 +356,11 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
       *(bf16x4*)(yrow + yo + cc) = o;
     }
   }
+  }
+  if constexpr (!SK) return;
+  if (head_first) head_first = false; else u += nk;
+  if (u >= sk_stop) return;
+  }   // next piece of this workgroup's run (SK)
 }
 
 // Which igemm5 configuration serves this problem (0: none): FN = 9 for column counts in 144-column halves, FN = 8 for 128-column halves;
@@ -283,9 +368,17 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
 // cut into up to 8 K-slices whose fp32 partial tiles the caller's workspace holds ([slice][row][column], summed by igemm4's combine
 // kernel) — and K must be long enough to amortise the two-tile prologue.  opt = rg_opt(RG_OPT_GEMM5): 0 heuristic, 1 wherever the
 // tiling allows, 2 also the 432-column layers (one of whose two column tiles is half empty), -1 off.
-struct G5Plan { int fn; int ksplit; };
-static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size_t ws_bytes, int cout_lanes) {
-  G5Plan pl = {0, 1};
+struct G5Plan { int fn; int ksplit; int sk; };
+// Stream-K (sk = workgroups, one per CU): the grid's tiles x K-tiles are cut into 256 equal contiguous runs instead of whole tiles, for grids whose last
+// round of tiles would leave much of the chip idle (CycleGAN: 256 -> 256 at 32^3 is 128 tiles forward, 154 backward — half a round and 0.6 of one).  A
+// run that starts inside a tile parks its fp32 partial in the caller's workspace (one slot per workgroup, accumulator-register order: fully coalesced)
+// and the workgroup that started that tile adds the 1-2 partials before the ordinary epilogue: no combine pass, ~0.7 partials per tile instead of
+// `ksplit` whole copies.  rg_opt(RG_OPT_SK): 0 heuristic, 1 wherever the tiling allows, -1 off.
+#define G5_SK_GRID 256
+#define G5_SK_ROWS 64       // flag rows (launches in flight on different streams use different rows; a row comes round again 64 stream-K launches later)
+static size_t g5_sk_bytes(int fn) { return (size_t)G5_SK_GRID * 4 * fn * 512 * 16; }
+static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size_t ws_bytes, int cout_lanes, bool sk_ok = true) {
+  G5Plan pl = {0, 1, 0};
   const int opt = rg_opt(RG_OPT_GEMM5);
   if (opt < 0 || flat || (wrows % 16) || cout_lanes < 8) return pl;
   const int nf = wrows / 16;
@@ -294,12 +387,24 @@ static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size
   const int bn = 2 * fn * 16;
   const long tiles_m = (M + G5_BM - 1) / G5_BM, tiles_n = (wrows + bn - 1) / bn;
   const long tiles = tiles_m * tiles_n * nbatch;
-  if (opt == 1) { pl.fn = fn; return pl; }
+  const int sko = rg_opt(RG_OPT_SK);
+  const bool sk_room = sk_ok && sko >= 0 && ws_bytes >= g5_sk_bytes(fn) && tiles * kunits >= G5_SK_GRID && tiles < (1L << 20);
+  if (opt == 1) { pl.fn = fn; if (sk_room && sko >= 1) pl.sk = G5_SK_GRID; return pl; }
   const double fill_n = (double)wrows / (double)(tiles_n * bn);
   // (batched GEMMs — the Winograd products — take a 75 %-full column tiling too: 64 x [1331 x 2592] x [2592 x 432] measured 0.295 ms here against 0.328 on igemm4)
   if (fill_n < ((opt == 2 || nbatch > 1) ? 0.70 : 0.88) || kunits < 8) return pl;
   auto round_fill = [](long t) { const double r = (double)t / 256.0; return r / (double)(long)(r + 0.999999); };
-  if (tiles >= 150 && round_fill(tiles) >= 0.70) { pl.fn = fn; return pl; }
+  // runs of >= 16 K-tiles (a run pays a two-tile prologue) and tiles long enough that a partial is small next to the work it saves
+  const bool sk_can = sk_room && (sko >= 1 || (kunits >= 16 && tiles * kunits >= (long)G5_SK_GRID * 16));
+  // Measured on 256 -> 256 at 32^3 (MI355X, us): backward, 154 tiles — whole tiles 182, igemm4 (192-row tiles) 200, stream-K 150; forward, 128 tiles —
+  // whole tiles 168, 2 K-slices + combine 121, stream-K 137 (with exactly two pieces per tile the hand-over is the combine pass run by half the
+  // chip while the other half idles).  So: K-slices where they tile the chip exactly, stream-K for the grids between whole rounds.
+  if (tiles >= 150 && round_fill(tiles) >= 0.70) {
+    pl.fn = fn;
+    if (sk_can && (sko >= 1 || (round_fill(tiles) < 0.75 && tiles <= 3 * 256))) pl.sk = G5_SK_GRID;
+    return pl;
+  }
+  if (sk_can && (sko >= 1 || tiles >= 150)) { pl.fn = fn; pl.sk = G5_SK_GRID; return pl; }
   if (nbatch == 1 && tiles < 150 && kunits >= 32 && (cout_lanes & 3) == 0) {   // split K: whole rounds of one workgroup per CU
     long ks = 256 / tiles; if (ks > 8) ks = 8; if (ks > kunits / 16) ks = kunits / 16;
     if (ks >= 2 && tiles * ks >= 150 && (size_t)ks * M * cout_lanes * 4 <= ws_bytes) { pl.fn = fn; pl.ksplit = (int)ks; }
@@ -314,7 +419,27 @@ bool rg_igemm5_wanted(const CL5& X, const CL5& Y, const rg_conv_params* p, size_
   const long M = (long)X.N * p->R[0] * p->R[1] * p->R[2];
   return g5_plan(M, round_up(p->cout, 16), (round_up(X.C, 64) >> 6) * p->T[0] * p->T[1] * p->T[2], 1, false, ws_bytes, Y.lanes).fn != 0;
 }
+// workspace a convolution needs for the stream-K schedule (0: that problem would not run stream-K even with the room)
+size_t rg_igemm5_sk_bytes(const CL5& X, const CL5& Y, const rg_conv_params* p) {
+  const long M = (long)X.N * p->R[0] * p->R[1] * p->R[2];
+  const G5Plan pl = g5_plan(M, round_up(p->cout, 16), (round_up(X.C, 64) >> 6) * p->T[0] * p->T[1] * p->T[2], 1, false, (size_t)1 << 40, Y.lanes);
+  return pl.sk ? g5_sk_bytes(pl.fn) : 0;
+}
 void rg_launch_igemm4_combine(const Igemm4Args& a, hipStream_t st);   // conv4.hip: y = act(sum of the K-slices' partial tiles + bias)
+
+// per-device flag rows of the stream-K schedule, zeroed once; epochs only grow, so nothing ever resets them
+static int* g5_sk_flag_rows() {
+  static std::mutex mu; static int* cache[64];
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cache[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)G5_SK_ROWS * G5_SK_GRID * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, (size_t)G5_SK_ROWS * G5_SK_GRID * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(p); return nullptr; }
+    cache[dev] = (int*)p;
+  }
+  return cache[dev];
+}
 
 int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_t ws_bytes) {
   const G5Plan pl = g5_plan(a.M, a.wrows, (a.cink >> 6) * a.TD * a.TH * a.TW, a.nbatch, false, ws_bytes, a.cout_lanes);
@@ -328,8 +453,29 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
     hipFuncSetAttribute((const void*)igemm5_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
     hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
     hipFuncSetAttribute((const void*)igemm5_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
   });
   if (a.d2s_c && pl.ksplit > 1) { rg_set_error("igemm5: depth-to-space epilogue with split-K"); return RG_ERR_UNSUPPORTED; }
+  if (pl.sk) {
+    static std::atomic<int> epoch{0};
+    int* rows = g5_sk_flag_rows();
+    if (!rows) { rg_set_error("igemm5: cannot allocate the stream-K flags"); return RG_ERR_HIP; }
+    const int e = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+    a.sk_grid = pl.sk; a.sk_part = ws; a.sk_epoch = e; a.sk_flags = rows + (size_t)((unsigned)e % G5_SK_ROWS) * G5_SK_GRID;
+    rg_set_kernel_name("igemm5_kernel<%d,%d>+streamK%s", (int)check, pl.fn, a.d2s_c ? "+d2s" : "");
+    const dim3 grid((unsigned)pl.sk);
+    if (pl.fn == 9) {
+      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+      else hipLaunchKernelGGL((igemm5_kernel<false, 9, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    } else {
+      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+      else hipLaunchKernelGGL((igemm5_kernel<false, 8, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    }
+    return RG_OK;
+  }
   rg_set_kernel_name("igemm5_kernel<%d,%d>%s", (int)check, pl.fn, pl.ksplit > 1 ? "+splitK" : (a.d2s_c ? "+d2s" : ""));
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * a.nbatch));
   if (pl.fn == 9) {

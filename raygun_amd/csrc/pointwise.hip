@@ -25,10 +25,10 @@ extern "C" int rg_version(void) { return 101; }
 #include <atomic>
 #include <mutex>
 #include <stdlib.h>
-static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5", "RG_NO_WGEMM", "RG_MWS_WGS", "RG_MWS_WMUL"};
+static const char* const g_opt_names[RG_OPT_COUNT] = {"RG_FM", "RG_NO_HALO", "RG_NO_THIN", "RG_NO_THIN3", "RG_NO_WLINES", "RG_NO_KWP", "RG_DEBUG_BOUNDS", "RG_GEMM5", "RG_NO_WGEMM", "RG_MWS_WGS", "RG_MWS_WMUL", "RG_SK"};
 static std::atomic<int> g_opt[RG_OPT_COUNT];
 static const bool g_opt_init = [] {   // environment -> switches, once, when the library is loaded
-  for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? ((i == RG_OPT_FM || i == RG_OPT_GEMM5 || i == RG_OPT_MWS_WGS || i == RG_OPT_MWS_WMUL) ? atoi(e) : (e[0] && e[0] != '0')) : 0); }
+  for (int i = 0; i < RG_OPT_COUNT; ++i) { const char* e = getenv(g_opt_names[i]); g_opt[i].store(e ? ((i == RG_OPT_FM || i == RG_OPT_GEMM5 || i == RG_OPT_MWS_WGS || i == RG_OPT_MWS_WMUL || i == RG_OPT_SK) ? atoi(e) : (e[0] && e[0] != '0')) : 0); }
   return true;
 }();
 int rg_opt(int which) { return which >= 0 && which < RG_OPT_COUNT ? g_opt[which].load(std::memory_order_relaxed) : 0; }

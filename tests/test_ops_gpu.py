@@ -617,7 +617,8 @@ def test_transposed_conv_subpixel_with_depth_to_space_epilogue(cin, cout, sp, ac
         monkeypatch.setenv("RAYGUN_AMD_D2S_EPILOGUE", flag)
         xd, wd = x0.clone().to(dev).requires_grad_(), w0.clone().to(dev).requires_grad_()
         ops.profile_start()
-        got = ops.conv_transpose3d(xd, wd, b0.to(dev), stride=2, padding=1, output_padding=1, act=act, slope=0.2)
+        with ops.option("RG_SK", -1):    # (the two-pass form has a workspace and may run stream-K — another summation order; the fused one never does)
+            got = ops.conv_transpose3d(xd, wd, b0.to(dev), stride=2, padding=1, output_padding=1, act=act, slope=0.2)
         names = list(ops.profile_stop())
         assert tuple(got.shape) == tuple(ref.shape)
         assert (got.float().cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item()), flag
@@ -928,6 +929,64 @@ def test_igemm5_lds_dma_conv_forward_and_backward_data(cin, cout, sp, k, stride,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,sp,k,pad,act,n", [
+    (256, 256, (18, 18, 18), 3, 0, "relu", 1),       # 16 tiles x 108 K-tiles over 256 workgroups: every tile is finished from ~16 partials
+    (128, 288, (40, 38, 40), 3, 1, "leaky", 1),      # 238 tiles x 54: runs of ~50 K-tiles = the tail of one tile + the head of the next; zero padding (CHECK); backward: ragged chunk (288 = 4.5 x 64)
+    (128, 256, (20, 50, 50), 3, 0, "none", 2),       # 324 tiles x 54: runs of 1.3 tiles — head piece first, then the tail, sometimes a WHOLE tile; N = 2
+    (256, 512, (11, 12, 13), 2, 0, "sigmoid", 1),    # two column tiles (tile order: rows fastest), 2^3 taps, 4 chunks: runs of 1-2 K-tiles (nk = 1 and 2)
+])
+def test_igemm5_stream_k_schedule(cin, cout, sp, k, pad, act, n):
+    """gemm5.hip stream-K (RG_SK=1 forces it wherever igemm5 runs): the (tile, K-tile) space cut into 256 equal runs, partial tiles handed over through
+    the workspace and per-workgroup flags.  Forward and backward-data against torch fp32 on the CPU, and against the whole-tile schedule (RG_SK=-1) —
+    shapes chosen so that runs are much shorter than a tile, about a tile, and longer than a tile."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((n, cin) + sp, 191); w0 = rnd((cout, cin, k, k, k), 192, -0.05, 0.05); b0 = rnd((cout,), 193)
+    afn = {"none": lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "leaky": lambda t: F.leaky_relu(t, 0.2)}[act]
+    xr = x0.clone().requires_grad_()
+    yr = afn(F.conv3d(xr, w0, b0, stride=1, padding=pad))
+    go = rnd(tuple(yr.shape), 194)
+    (gxr,) = torch.autograd.grad(yr, xr, go)
+    outs = {}
+    for sk in (1, -1, 1):      # twice with stream-K: the second launch finds the flags of the first (epochs, not resets)
+        with ops.option("RG_GEMM5", 1), ops.option("RG_SK", sk):
+            xd = x0.clone().to(dev).requires_grad_()
+            y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, pad, act, 0.2)
+            name = _lib.lib().rg_last_kernel_name().decode()
+            assert ("streamK" in name) == (sk == 1) and "igemm5" in name, name
+            ops.profile_start()           # (the backward pass runs on autograd's thread: rg_last_kernel_name is per thread, the profile list is not)
+            (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+            names = [n for n in ops.profile_stop() if "igemm" in n]
+            assert names and all(("streamK" in n) == (sk == 1) and "igemm5" in n for n in names), names
+            assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL, (sk, relerr(y, yr), relerr(gx, gxr))
+            if sk in outs:   # the schedule is fixed by the shape: bit-identical from launch to launch
+                assert torch.equal(outs[sk][0], y.float().cpu()) and torch.equal(outs[sk][1], gx.float().cpu())
+            outs[sk] = (y.float().cpu(), gx.float().cpu())
+    assert relerr(outs[1][0], outs[-1][0]) <= 2 ** -7 and relerr(outs[1][1], outs[-1][1]) <= 2 ** -7
+
+
+@pytest.mark.gpu
+def test_stream_k_is_the_default_for_the_resnet_block_backward():
+    """The CycleGAN generator's 256 -> 256 blocks at 32^3 (reflect-padded to 34^3): 128 row tiles forward — two K-slices tile the chip exactly —
+    and 154 backward, 0.6 of a round: that one runs stream-K by default; results within rounding of the whole-tile kernels."""
+    from raygun_amd import _lib, ops
+    dev = torch.device("cuda")
+    x0 = rnd((1, 256, 34, 34, 34), 195).to(dev); w0 = rnd((256, 256, 3, 3, 3), 196, -0.02, 0.02).to(dev); b0 = rnd((256,), 197).to(dev)
+    outs = {}
+    for sk in (0, -1):
+        with ops.option("RG_SK", sk):
+            xd = x0.clone().requires_grad_()
+            y = ops.conv3d(xd, w0, b0, 1, 0, "none", 0.0)
+            n1 = _lib.lib().rg_last_kernel_name().decode()
+            ops.profile_start()
+            (gx,) = torch.autograd.grad(y, xd, torch.ones_like(y))
+            n2 = [n for n in ops.profile_stop() if "igemm" in n]
+            assert "splitK" in n1 and len(n2) == 1 and ("streamK" in n2[0]) == (sk == 0), (n1, n2)
+            outs[sk] = (y.float().cpu(), gx.float().cpu())
+    assert relerr(outs[0][1], outs[-1][1]) <= 2 ** -7
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,m,k,n", [(2, 300, 200, 288), (3, 700, 2592, 576), (1, 257, 64, 144), (2, 1000, 448, 432)])
 def test_gemm_batched_on_igemm5(B, m, k, n):
     """rg_gemm_batched (the Winograd path's 64 transform-domain GEMMs) on igemm5 and on igemm4 against torch.matmul in fp32."""
@@ -976,7 +1035,8 @@ def test_wgrad_wide_tiles_ragged_shapes(cin, cout, sp, k, pad, n):
 def test_igemm5_split_k_small_grid():
     """igemm5 with K-slices (the 256 -> 256 ResNet-block convolution of the CycleGAN at 32^3: 128 row tiles x 1 column tile, K = 108
     tiles -> 2 slices, fp32 partial tiles through the workspace, igemm4's combine kernel adds bias + activation): forward and
-    backward-data against torch fp32 on the CPU; the heuristic (RG_GEMM5 = 0) must pick the split by itself."""
+    backward-data against torch fp32 on the CPU.  Since round 4 the stream-K schedule takes this shape by default; the K-slices remain
+    what the heuristic picks with stream-K off (RG_SK = -1) and for callers whose workspace only holds the slices."""
     from raygun_amd import _lib, ops
     dev = torch.device("cuda")
     x0 = rnd((1, 256, 34, 34, 34), 101); w0 = rnd((256, 256, 3, 3, 3), 102, -0.02, 0.02); b0 = rnd((256,), 103)
@@ -984,11 +1044,12 @@ def test_igemm5_split_k_small_grid():
     yr = torch.relu(F.conv3d(xr, w0, b0))
     go = rnd(tuple(yr.shape), 104)
     (gxr,) = torch.autograd.grad(yr, xr, go)
-    xd = x0.clone().to(dev).requires_grad_()
-    y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, 0, "relu")
-    name = _lib.lib().rg_last_kernel_name().decode()
-    assert "igemm5" in name and "splitK" in name, name
-    (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+    with ops.option("RG_SK", -1):
+        xd = x0.clone().to(dev).requires_grad_()
+        y = ops.conv3d(xd, w0.to(dev), b0.to(dev), 1, 0, "relu")
+        name = _lib.lib().rg_last_kernel_name().decode()
+        assert "igemm5" in name and "splitK" in name, name
+        (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
     assert relerr(y, yr) <= TOL and relerr(gx, gxr) <= TOL, (relerr(y, yr), relerr(gx, gxr))
 
 
