@@ -41,6 +41,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 rg_h8;
 #define RG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rg_h8, (a)), __builtin_bit_cast(rg_h8, (b)), (c), 0, 0, 0)
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }  // v_cvt_f16_f32: RNE, overflow -> inf, NaN stays NaN
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 #else
 #define RG_ACT_DTYPE RG_BF16
 #define RG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
@@ -52,6 +53,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// two values in one instruction (gfx950 v_cvt_pk_bf16_f32: round to nearest even like f2bf; NaN stays a quiet NaN) — for epilogues that convert whole tiles
+typedef __bf16 rg_bf2 __attribute__((ext_vector_type(2)));
+typedef float rg_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((rg_f2){lo, hi}, rg_bf2)); }
 #endif
 
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
@@ -62,6 +67,24 @@ __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
     return v < 0.f ? neg : v;   // (this form hands a NaN on, like torch.relu; `v > 0 ? v : neg` would turn it into 0 and hide an overflow)
   }
   return act == RG_ACT_SIGMOID ? 1.f / (1.f + __expf(-v)) : tanhf(v);
+}
+// Convolution epilogues convert whole accumulator tiles; a generic act_fwd per element under a per-lane `channel < cout` test makes the compiler
+// predicate 100+ inlined tanh / exp bodies (gemm5.hip measured 17 us per 256 x 256 tile for that form, 2.5 us for this one).  They run one of two
+// instantiations instead: LIN = the piecewise-linear activations (none / ReLU / LeakyReLU) as one multiply + select with nslope = rg_act_nslope(),
+// or the transcendental ones through act_fwd.  One accumulator quad -> 4 stored channels: + bias, activation, zeros for channels >= live.
+__device__ __forceinline__ float rg_act_nslope(int act, float slope) { return act == RG_ACT_RELU ? 0.f : (act == RG_ACT_LEAKY ? slope : 1.f); }
+template <bool LIN>
+__device__ __forceinline__ uint2 rg_epilogue_quad(const f32x4 acc, const float* bv, int live, float nslope, int act, float slope) {
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = acc[r] + bv[r];
+    if constexpr (LIN) x = x < 0.f ? x * nslope : x;      // (hands a NaN on, like act_fwd)
+    else x = act_fwd(x, act, slope);
+    v[r] = r < live ? x : 0.f;
+  }
+  uint2 o; o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+  return o;
 }
 // derivative expressed through the OUTPUT y of the activation
 __device__ __forceinline__ float act_bwd_from_y(float y, int act, float slope) {

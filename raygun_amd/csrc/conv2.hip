@@ -17,6 +17,7 @@
 //     tile is shared by the 4 waves.  One barrier per K-step.
 // One workgroup per CU (up to 106 KB LDS, 1 wave per SIMD with the whole register file).
 #include "common.h"
+#include <type_traits>
 #include <utility>
 #include <stdlib.h>
 
@@ -226,34 +227,31 @@ __global__ __launch_bounds__(256, (BM == 128 ? 2 : 1)) void igemm2_kernel(Igemm2
     stage ^= 1;
   }
 
-  // ---- epilogue: lane holds channels c..c+3 of voxel (lane&15) for every fragment
+  // ---- epilogue: lane holds channels c..c+3 of voxel (lane&15) for every fragment (two instantiations: common.h rg_epilogue_quad)
+  const float nslope = rg_act_nslope(a.act, a.slope);
+  auto finish = [&](auto LIN) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const long m = m0 + wave * (BM / 4) + i * 16 + fr;
-    if (m >= a.M) continue;
-    long t = m;
-    const int rw = (int)(t % a.RW); t /= a.RW;
-    const int rh = (int)(t % a.RH); t /= a.RH;
-    const int rd = (int)(t % a.RD); t /= a.RD;
-    bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
-                   (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+    for (int i = 0; i < FM; ++i) {
+      const long m = m0 + wave * (BM / 4) + i * 16 + fr;
+      if (m >= a.M) continue;
+      long t = m;
+      const int rw = (int)(t % a.RW); t /= a.RW;
+      const int rh = (int)(t % a.RH); t /= a.RH;
+      const int rd = (int)(t % a.RD); t /= a.RD;
+      bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+                     (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int c = n0 + j * 16 + fg * 4;
-      if (c >= a.cout_lanes) continue;
-      bf16x4 o;
+      for (int j = 0; j < FN; ++j) {
+        const int c = n0 + j * 16 + fg * 4;
+        if (c >= a.cout_lanes) continue;
+        float bv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-        if (c + r < a.cout) {
-          v = acc[i][j][r] + (a.bias ? a.bias[c + r] : 0.f);
-          v = act_fwd(v, a.act, a.slope);
-        }
-        o[r] = (short)f2bf(v);
+        for (int r = 0; r < 4; ++r) bv[r] = (a.bias && c + r < a.cout) ? a.bias[c + r] : 0.f;
+        *(uint2*)(yrow + c) = rg_epilogue_quad<decltype(LIN)::value>(acc[i][j], bv, a.cout - c, nslope, a.act, a.slope);
       }
-      *(bf16x4*)(yrow + c) = o;
     }
-  }
+  };
+  if (a.act <= RG_ACT_LEAKY) finish(std::true_type{}); else finish(std::false_type{});
 }
 
 template <int BM, int FN>

@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(Igemm3Args a) {
     if (++kw == a.TW) { kw = 0; ++grp; aadvance(); }
   }
 
-  // ---- epilogue
+  // ---- epilogue (common.h rg_epilogue_quad: the piecewise-linear activations as straight-line code)
+  const bool lin = a.act <= RG_ACT_LEAKY;
+  const float nslope = rg_act_nslope(a.act, a.slope);
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int r = wave * 32 + i * 16 + fr;
@@ -232,14 +234,11 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(Igemm3Args a) {
     for (int j = 0; j < FN; ++j) {
       const int c = n0 + j * 16 + fg * 4;
       if (c >= a.cout_lanes) continue;
-      bf16x4 o;
+      float bv[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float v = 0.f;
-        if (c + rr < a.cout) { v = acc[i][j][rr] + (a.bias ? a.bias[c + rr] : 0.f); v = act_fwd(v, a.act, a.slope); }
-        o[rr] = (short)f2bf(v);
-      }
-      *(bf16x4*)(yrow + c) = o;
+      for (int rr = 0; rr < 4; ++rr) bv[rr] = (a.bias && c + rr < a.cout) ? a.bias[c + rr] : 0.f;
+      *(uint2*)(yrow + c) = lin ? rg_epilogue_quad<true>(acc[i][j], bv, a.cout - c, nslope, a.act, a.slope)
+                                : rg_epilogue_quad<false>(acc[i][j], bv, a.cout - c, nslope, a.act, a.slope);
     }
   }
 }

@@ -298,33 +298,37 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const long m = m0 + wave * (16 * FM) + i * 16 + fr;
-    if (m >= a.M) continue;
-    long t = m;
-    const int rw = (int)(t % a.RW); t /= a.RW;
-    const int rh = (int)(t % a.RH); t /= a.RH;
-    const int rd = (int)(t % a.RD); t /= a.RD;
-    bf16_t* yrow = ybase + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
-                   (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+  // two instantiations: the piecewise-linear activations (none / ReLU / LeakyReLU: one multiply and one select per element) as straight-line code,
+  // the transcendental ones apart — a generic act_fwd per element under the per-lane `channel < cout` test expands into thousands of predicated
+  // instructions (gemm5.hip measured 17 us per 256 x 256 tile for that form)
+  const float nslope = rg_act_nslope(a.act, a.slope);
+  auto finish = [&](auto TR) {
+    float bv[FN][4];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int c = n0 + j * 16 + fg * 4;
-      if (c >= a.cout_lanes) continue;
-      bf16x4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-        if (c + r < a.cout) {
-          v = acc[i][j][r] + (a.bias ? a.bias[c + r] : 0.f);
-          v = act_fwd(v, a.act, a.slope);
-        }
-        o[r] = (short)f2bf(v);
-      }
-      *(bf16x4*)(yrow + c) = o;
+      for (int r = 0; r < 4; ++r) bv[j][r] = (a.bias && c + r < a.cout) ? a.bias[c + r] : 0.f;
     }
-  }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const long m = m0 + wave * (16 * FM) + i * 16 + fr;
+      if (m >= a.M) continue;
+      long t = m;
+      const int rw = (int)(t % a.RW); t /= a.RW;
+      const int rh = (int)(t % a.RH); t /= a.RH;
+      const int rd = (int)(t % a.RD); t /= a.RD;
+      bf16_t* yrow = ybase + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
+                     (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = n0 + j * 16 + fg * 4;
+        if (c >= a.cout_lanes) continue;
+        *(uint2*)(yrow + c) = rg_epilogue_quad<!decltype(TR)::value>(acc[i][j], bv[j], a.cout - c, nslope, a.act, a.slope);
+      }
+    }
+  };
+  if (a.act <= RG_ACT_LEAKY) finish(std::false_type{}); else finish(std::true_type{});
 }
 
 // y[row][c] = act(sum_s part[s][row][c] + bias[c]) for a split-K launch: one thread per (row, 4 channels), splits summed in order
@@ -344,14 +348,11 @@ __global__ __launch_bounds__(256) void igemm4_combine_kernel(Igemm4Args a) {
     const int rd = (int)(t % a.RD); t /= a.RD;
     bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
                    (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
-    bf16x4 o;
+    float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x = 0.f;
-      if (c + r < a.cout) x = act_fwd(v[r] + (a.bias ? a.bias[c + r] : 0.f), a.act, a.slope);
-      o[r] = (short)f2bf(x);
-    }
-    *(bf16x4*)(yrow + c) = o;
+    for (int r = 0; r < 4; ++r) bv[r] = (a.bias && c + r < a.cout) ? a.bias[c + r] : 0.f;
+    *(uint2*)(yrow + c) = a.act <= RG_ACT_LEAKY ? rg_epilogue_quad<true>(v, bv, a.cout - c, rg_act_nslope(a.act, a.slope), a.act, a.slope)
+                                                 : rg_epilogue_quad<false>(v, bv, a.cout - c, 0.f, a.act, a.slope);
   }
 }
 void rg_launch_igemm4_combine(const Igemm4Args& a, hipStream_t st) {
@@ -658,14 +659,8 @@ __global__ __launch_bounds__(256) void igemm_thin_kernel(Igemm4Args a) {
       bf16_t* yrow = a.y + yoff[i];
       const int c = fg * 4;
       if (c >= a.cout_lanes) continue;
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-        if (c + r < a.cout) v = act_fwd(acc[i][r] + bias4[r], a.act, a.slope);
-        o[r] = (short)f2bf(v);
-      }
-      *(bf16x4*)(yrow + c) = o;
+      *(uint2*)(yrow + c) = a.act <= RG_ACT_LEAKY ? rg_epilogue_quad<true>(acc[i], bias4, a.cout - c, rg_act_nslope(a.act, a.slope), a.act, a.slope)
+                                                   : rg_epilogue_quad<false>(acc[i], bias4, a.cout - c, 0.f, a.act, a.slope);
     }
   }
 }
@@ -805,14 +800,8 @@ __global__ __launch_bounds__(256) void igemm_thin3_kernel(Igemm4Args a) {
       bf16_t* yrow = a.y + yoff[i];
       const int c = fg * 4;
       if (c >= a.cout_lanes) continue;
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-        if (c + r < a.cout) v = act_fwd(acc[i][r] + bias4[r], a.act, a.slope);
-        o[r] = (short)f2bf(v);
-      }
-      *(bf16x4*)(yrow + c) = o;
+      *(uint2*)(yrow + c) = a.act <= RG_ACT_LEAKY ? rg_epilogue_quad<true>(acc[i], bias4, a.cout - c, rg_act_nslope(a.act, a.slope), a.act, a.slope)
+                                                   : rg_epilogue_quad<false>(acc[i], bias4, a.cout - c, 0.f, a.act, a.slope);
     }
   }
 }

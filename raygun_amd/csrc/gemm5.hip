@@ -33,6 +33,8 @@ typedef int g5_i32x4 __attribute__((ext_vector_type(4)));
 #define G5_BROWS 320                       // B rows a stage holds (FN = 9: 288 used, 5 DMA instructions; FN = 8: 256 used, 4 instructions)
 #define G5_STAGE ((G5_BM + G5_BROWS) * 128) // bytes per stage
 #define G5_OOB 0x80000000u
+// dynamic LDS: the two stages, or the epilogue's 16-bit tile (256 rows of BN * 2 + 16 bytes) + row table, whichever is larger (FN = 9: 150 KiB of the CU's 160)
+#define G5_LDS_BYTES(fn) ((2 * G5_STAGE) > (256 * (2 * (fn) * 16 * 2 + 16) + 2048) ? (2 * G5_STAGE) : (256 * (2 * (fn) * 16 * 2 + 16) + 2048))
 
 __device__ __forceinline__ g5_i32x4 g5_rsrc(const void* base, unsigned nrec) {
   const unsigned long b = (unsigned long)base;
@@ -122,13 +124,13 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   for (int i = 0; i < 4; ++i) {
     const long m = m0 + i * 64 + drow;
     const bool v = m < a.M;
-    long t = v ? m : 0;
-    const int rw_ = (int)(t % a.RW); t /= a.RW;
-    const int rh_ = (int)(t % a.RH); t /= a.RH;
-    const int rd_ = (int)(t % a.RD); t /= a.RD;
+    unsigned t = v ? (unsigned)m : 0u;      // (M < 2^31: g5_plan; 32-bit divisions — the 64-bit ones were 3 of the 4 us this setup took)
+    const int rw_ = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+    const int rh_ = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd_ = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
     rd0[i] = rd_ * a.rs[0] + a.tb[0]; rh0[i] = rh_ * a.rs[1] + a.tb[1]; rw0[i] = rw_ * a.rs[2] + a.tb[2];
     // tap offsets are added later and may be negative: valid rows stay inside [0, 2^30), parked rows stay out of range
-    va[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + dpiece * 8) * 2) : G5_OOB;
+    va[i] = v ? (unsigned)(((long)t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + dpiece * 8) * 2) : G5_OOB;
     if (!v) { rd0[i] = rh0[i] = rw0[i] = -(1 << 20); }
   }
 #pragma unroll
@@ -177,7 +179,6 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   // ---- prologue: A(0), B(0) -> stage 0, A(1) -> stage 1 (stays in flight)
   const bool two = nk > 1;
   prep_a(); dma_a(0, C0{}); dma_a(0, C1{}); dma_a(0, C2{}); dma_a(0, C3{});
@@ -323,39 +324,85 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
     }
   }
   if (finish) {
-  bf16_t* const ybase = a.y + batch * a.ybatch;
+    // The 16-bit tile goes through LDS (free once every wave has left the K loop): each lane converts its 4 x FN accumulators (bias, activation,
+    // rounding) into row-major [256][BN] with a 16-byte row pad (ds_write_b64, banks evenly loaded), thread r < 256 decodes output row r ONCE into a
+    // table, and the tile leaves as 16-byte pieces — consecutive lanes = consecutive channels of one voxel, whole 128-byte lines — instead of 8-byte
+    // pieces 16 rows apart with a row decode (three 64-bit divisions) per accumulator row.  Per tile: 17 us (conversion) + 3 us (stores) became 2.5 + 3 us.
+    constexpr int EP = G5_BN * 2 + 16;                      // bytes per LDS row
+    unsigned char* const etile = g5_lds;
+    long* const erow = (long*)(g5_lds + 256 * EP);          // element offset of the row's voxel in y, -1: past M
+    bf16_t* const ybase = a.y + batch * a.ybatch;
+    if (etid < 256) {
+      const long m = m0 + etid;
+      long off = -1;
+      if (m < a.M) {
+        unsigned t = (unsigned)m;
+        const int rw_ = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+        const int rh_ = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+        const int rd_ = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
+        off = (long)t * a.ysn + (long)(rd_ * a.os[0] + a.oo[0]) * a.ysd + (long)(rh_ * a.os[1] + a.oo[1]) * a.ysh + (long)(rw_ * a.os[2] + a.oo[2]) * a.ysw;
+      }
+      erow[etid] = off;
+    }
+    const bool bias_v4 = a.bias && (((unsigned long)a.bias & 15) == 0);
+    // two instantiations of the conversion: the piecewise-linear activations as straight-line code (none / ReLU / LeakyReLU = one multiply and one
+    // select), the transcendental ones apart — one generic act_fwd per element under the per-lane `channel < cout` test expanded into 13 000
+    // predicated instructions and took 17 of the 33 us a tile cost beyond its K loop
+    const float nslope = a.act == RG_ACT_RELU ? 0.f : (a.act == RG_ACT_LEAKY ? a.slope : 1.f);
+    auto convert = [&](auto TR) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long m = m0 + wm * 64 + i * 16 + efr;
-    if (m >= a.M) continue;
-    long t = m;
-    const int rw_ = (int)(t % a.RW); t /= a.RW;
-    const int rh_ = (int)(t % a.RH); t /= a.RH;
-    const int rd_ = (int)(t % a.RD); t /= a.RD;
-    bf16_t* yrow = ybase + t * a.ysn + (long)(rd_ * a.os[0] + a.oo[0]) * a.ysd + (long)(rh_ * a.os[1] + a.oo[1]) * a.ysh +
-                   (long)(rw_ * a.os[2] + a.oo[2]) * a.ysw;
+      for (int j = 0; j < FN; ++j) {
+        const int cl = wn * (FN * 16) + j * 16 + efg * 4;     // column within the tile
+        const int c = n0 + cl;
+        int cc = c;
+        if (a.d2s_c) cc = c % a.d2s_c;                        // bias per channel of the parity block
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+          if (bias_v4 && c + 3 < a.cout) { const f32x4 b4 = *(const f32x4*)(a.bias + cc); bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3]; }
+          else {
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int c = n0 + wn * (FN * 16) + j * 16 + efg * 4;
-      if (c >= a.cout_lanes) continue;
+            for (int r = 0; r < 4; ++r) if (c + r < a.cout) bv[r] = a.bias[cc + r];
+          }
+        }
+        const int live = a.cout - c;                          // channels c .. c + live - 1 exist; the pad lanes behind them are written as zeros
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][j][r] + bv[r];
+            if constexpr (decltype(TR)::value) x = act_fwd(x, a.act, a.slope);
+            else x = x < 0.f ? x * nslope : x;                // (hands a NaN on, like act_fwd)
+            v[r] = r < live ? x : 0.f;
+          }
+          uint2 o; o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+          *(uint2*)(etile + (wm * 64 + i * 16 + efr) * EP + cl * 2) = o;
+        }
+      }
+    };
+    if (a.act <= RG_ACT_LEAKY) convert(std::false_type{}); else convert(std::true_type{});
+    __syncthreads();
+    constexpr int PPR = G5_BN / 8;                          // 16-byte pieces per row
+#pragma unroll 2
+    for (int pidx = etid; pidx < 256 * PPR; pidx += 512) {
+      const int row = pidx / PPR, q8 = pidx - row * PPR;
+      const int c = n0 + q8 * 8;
+      const long off = erow[row];
+      if (off < 0 || c >= a.cout_lanes) continue;
       int cc = c; long yo = 0;
-      if (a.d2s_c) {   // depth-to-space: column block q = c / C is parity (qd, qh, qw) of output voxel 2 * row + parity (the 4 columns share q: C % 16 == 0)
+      if (a.d2s_c) {   // depth-to-space: column block q = c / C is parity (qd, qh, qw) of output voxel 2 * row + parity (a piece never straddles blocks: C % 16 == 0)
         const int q = c / a.d2s_c; cc = c - q * a.d2s_c;
         yo = (long)((q >> 2) & 1) * a.ysd + (long)((q >> 1) & 1) * a.ysh + (long)(q & 1) * a.ysw;
       }
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = 0.f;
-        if (c + r < a.cout) {
-          v = acc[i][j][r] + (a.bias ? a.bias[cc + r] : 0.f);
-          v = act_fwd(v, a.act, a.slope);
-        }
-        o[r] = (short)f2bf(v);
+      const u32x4_t v = *(const u32x4_t*)(etile + row * EP + q8 * 16);
+      bf16_t* dst = ybase + off + yo + cc;
+      if (c + 8 <= a.cout_lanes && (((unsigned long)dst & 15) == 0)) *(u32x4_t*)dst = v;
+      else {   // a view whose voxel pitch or channel offset is not a multiple of 8 lanes, or the last lanes of a row: 8-byte halves
+        *(unsigned long*)dst = ((unsigned long)v[1] << 32) | v[0];
+        if (c + 4 < a.cout_lanes) *(unsigned long*)(dst + 4) = ((unsigned long)v[3] << 32) | v[2];
       }
-      *(bf16x4*)(yrow + yo + cc) = o;
     }
-  }
+    if constexpr (SK) __syncthreads();                      // the next piece's DMA overwrites this LDS
   }
   if constexpr (!SK) return;
   if (head_first) head_first = false; else u += nk;
@@ -380,7 +427,7 @@ static size_t g5_sk_bytes(int fn) { return (size_t)G5_SK_GRID * 4 * fn * 512 * 1
 static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size_t ws_bytes, int cout_lanes, bool sk_ok = true) {
   G5Plan pl = {0, 1, 0};
   const int opt = rg_opt(RG_OPT_GEMM5);
-  if (opt < 0 || flat || (wrows % 16) || cout_lanes < 8) return pl;
+  if (opt < 0 || flat || (wrows % 16) || cout_lanes < 8 || M >= (1L << 31)) return pl;   // (the kernel decodes rows with 32-bit divisions)
   const int nf = wrows / 16;
   const int fn = nf % 9 == 0 ? 9 : (nf % 8 == 0 ? 8 : 0);
   if (!fn) return pl;
@@ -449,14 +496,14 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
   a.ksplit = pl.ksplit; a.part = pl.ksplit > 1 ? ws : nullptr;
   static rg_device_latch attr;
   rg_once_per_device(&attr, [] {
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(9));
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(9));
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(8));
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(8));
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(9));
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 9, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(9));
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(8));
+    hipFuncSetAttribute((const void*)igemm5_kernel<true, 8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(8));
   });
   if (a.d2s_c && pl.ksplit > 1) { rg_set_error("igemm5: depth-to-space epilogue with split-K"); return RG_ERR_UNSUPPORTED; }
   if (pl.sk) {
@@ -468,22 +515,22 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
     rg_set_kernel_name("igemm5_kernel<%d,%d>+streamK%s", (int)check, pl.fn, a.d2s_c ? "+d2s" : "");
     const dim3 grid((unsigned)pl.sk);
     if (pl.fn == 9) {
-      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
-      else hipLaunchKernelGGL((igemm5_kernel<false, 9, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9, false, true>), grid, dim3(512), G5_LDS_BYTES(9), st, a);
+      else hipLaunchKernelGGL((igemm5_kernel<false, 9, false, true>), grid, dim3(512), G5_LDS_BYTES(9), st, a);
     } else {
-      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
-      else hipLaunchKernelGGL((igemm5_kernel<false, 8, false, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+      if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8, false, true>), grid, dim3(512), G5_LDS_BYTES(8), st, a);
+      else hipLaunchKernelGGL((igemm5_kernel<false, 8, false, true>), grid, dim3(512), G5_LDS_BYTES(8), st, a);
     }
     return RG_OK;
   }
   rg_set_kernel_name("igemm5_kernel<%d,%d>%s", (int)check, pl.fn, pl.ksplit > 1 ? "+splitK" : (a.d2s_c ? "+d2s" : ""));
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.ksplit * a.nbatch));
   if (pl.fn == 9) {
-    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
-    else hipLaunchKernelGGL((igemm5_kernel<false, 9>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 9>), grid, dim3(512), G5_LDS_BYTES(9), st, a);
+    else hipLaunchKernelGGL((igemm5_kernel<false, 9>), grid, dim3(512), G5_LDS_BYTES(9), st, a);
   } else {
-    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
-    else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), 2 * G5_STAGE, st, a);
+    if (check) hipLaunchKernelGGL((igemm5_kernel<true, 8>), grid, dim3(512), G5_LDS_BYTES(8), st, a);
+    else hipLaunchKernelGGL((igemm5_kernel<false, 8>), grid, dim3(512), G5_LDS_BYTES(8), st, a);
   }
   if (a.ksplit > 1) rg_launch_igemm4_combine(a, st);
   return RG_OK;
@@ -597,13 +644,13 @@ int rg_launch_wgrad_gemm(const CL5& G, const CL5& X, const rg_conv_params* p, fl
   a.tiles_n = (a.wrows + bn - 1) / bn;
   static rg_device_latch attr;
   rg_once_per_device(&attr, [] {
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
-    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G5_STAGE);
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 9, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(9));
+    hipFuncSetAttribute((const void*)igemm5_kernel<false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G5_LDS_BYTES(8));
   });
   rg_set_kernel_name("wgrad_gemm_igemm5_kernel<0,%d,1>", pl.fn);
   const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.nbatch));
-  if (pl.fn == 9) hipLaunchKernelGGL((igemm5_kernel<false, 9, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
-  else hipLaunchKernelGGL((igemm5_kernel<false, 8, true>), grid, dim3(512), 2 * G5_STAGE, st, a);
+  if (pl.fn == 9) hipLaunchKernelGGL((igemm5_kernel<false, 9, true>), grid, dim3(512), G5_LDS_BYTES(9), st, a);
+  else hipLaunchKernelGGL((igemm5_kernel<false, 8, true>), grid, dim3(512), G5_LDS_BYTES(8), st, a);
   rg_prof_mark(st);
   return RG_OK;
 }

@@ -147,6 +147,8 @@ __global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, const 
     be[k] = 0.f;
     if (ab && c < x.C) { r[k] *= ab[2 * c]; be[k] = ab[2 * c + 1]; }
   }
+  const bool lin = act <= RG_ACT_LEAKY;
+  const float nslope = rg_act_nslope(act, slope);
   const unsigned nvox = (unsigned)(y.D * y.H * y.W);
   const unsigned v0 = blockIdx.x * (unsigned)vpb;
   unsigned v1 = v0 + (unsigned)vpb; if (v1 > nvox) v1 = nvox;
@@ -170,7 +172,11 @@ __global__ void norm_apply_kernel(CL5 x, CL5 res, CL5 y, const float* mr, const 
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float val = 0.f;
-        if (grp * 8 + k < x.C) val = act_fwd((bf2f((bf16_t)xv[u][k]) - m[k]) * r[k] + be[k], act, slope) + bf2f((bf16_t)rv[u][k]);
+        {   // (the piecewise-linear activations as multiply + select; a generic act_fwd under the per-lane channel test predicates 32 inlined tanh bodies)
+          const float xh = (bf2f((bf16_t)xv[u][k]) - m[k]) * r[k] + be[k];
+          const float av = lin ? (xh < 0.f ? xh * nslope : xh) : act_fwd(xh, act, slope);
+          val = grp * 8 + k < x.C ? av + bf2f((bf16_t)rv[u][k]) : 0.f;
+        }
         o[k] = (short)f2bf(val);
       }
       *(bf16x8*)(y.p + vox_off(y, n, v, dense) + grp * 8) = o;
