@@ -69,6 +69,8 @@ def build_unet(dev, size, seed, precision="bf16"):
         model = MTLSDModel(num_affs=3)
     loss_fn = WeightedMSELoss_MTLSD()
     opt = FusedAdam(model.parameters(), lr=0.5e-4)
+    if precision != "f16" and parallel.world_size() == 1 and os.environ.get("RAYGUN_AMD_ADAM_OVERLAP", "0") == "1":
+        opt.overlap_backward()   # opt-in, as in train_step (raygun_amd/torch/train/driver.py): measured 22.38 ms against 22.19 without
     raw = torch.from_numpy(synth.uniform((1, 1, size, size, size), 42 + seed)).to(dev)
     out = 8 * ((size - 92) // 8)
     gt_a = torch.from_numpy(synth.uniform((1, 3, out, out, out), 142 + seed, 0, 1)).to(dev)

@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256, (BM == 128 ? 2 : 1)) void igemm2_kernel(Igemm2
     const long m = m0 + row;
     const bool v = m < a.M;
     rvalid |= (unsigned)v << i;
-    long t = v ? m : 0;
-    const int rw = (int)(t % a.RW); t /= a.RW;
-    const int rh = (int)(t % a.RH); t /= a.RH;
-    const int rd = (int)(t % a.RD); t /= a.RD;
+    unsigned t = v ? (unsigned)m : 0u;   // (M < 2^31, checked by the launcher: 32-bit divisions)
+    const int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
     rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
     rbase[i] = (int)(t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw);
   }
@@ -234,10 +234,10 @@ __global__ __launch_bounds__(256, (BM == 128 ? 2 : 1)) void igemm2_kernel(Igemm2
     for (int i = 0; i < FM; ++i) {
       const long m = m0 + wave * (BM / 4) + i * 16 + fr;
       if (m >= a.M) continue;
-      long t = m;
-      const int rw = (int)(t % a.RW); t /= a.RW;
-      const int rh = (int)(t % a.RH); t /= a.RH;
-      const int rd = (int)(t % a.RD); t /= a.RD;
+      unsigned t = (unsigned)m;
+      const int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+      const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+      const int rd = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
       bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
                      (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll

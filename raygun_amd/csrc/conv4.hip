@@ -85,10 +85,10 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
   for (int i = 0; i < FM; ++i) {
     const long m = m0 + wave * (16 * FM) + i * 16 + fr;
     const bool v = m < a.M;
-    long t = v ? m : 0;
-    const int rw = (int)(t % a.RW); t /= a.RW;
-    const int rh = (int)(t % a.RH); t /= a.RH;
-    const int rd = (int)(t % a.RD); t /= a.RD;
+    unsigned t = v ? (unsigned)m : 0u;   // (M < 2^31, checked by the launcher: 32-bit divisions)
+    const int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
     rd0[i] = rd * a.rs[0] + a.tb[0]; rh0[i] = rh * a.rs[1] + a.tb[1]; rw0[i] = rw * a.rs[2] + a.tb[2];
     // tap offsets are added later and may be negative: keep the sum inside [0, 2^31) for valid lanes, park invalid rows
     rbase[i] = v ? (unsigned)((t * a.xsn + rd0[i] * a.xsd + rh0[i] * a.xsh + rw0[i] * a.xsw + (FLAT ? 0 : fg * 8)) * 2) : IG4_OOB;
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256, (FM >= 3 ? 2 : (FM == 1 ? 4 : 3))) void igemm4
     for (int i = 0; i < FM; ++i) {
       const long m = m0 + wave * (16 * FM) + i * 16 + fr;
       if (m >= a.M) continue;
-      long t = m;
-      const int rw = (int)(t % a.RW); t /= a.RW;
-      const int rh = (int)(t % a.RH); t /= a.RH;
-      const int rd = (int)(t % a.RD); t /= a.RD;
+      unsigned t = (unsigned)m;
+      const int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+      const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+      const int rd = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
       bf16_t* yrow = ybase + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
                      (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
 #pragma unroll
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(256) void igemm4_combine_kernel(Igemm4Args a) {
       const f32x4 u = *(const f32x4*)(a.part + ((long)sp * a.M + m) * a.cout_lanes + c);
       v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
     }
-    long t = m;
-    const int rw = (int)(t % a.RW); t /= a.RW;
-    const int rh = (int)(t % a.RH); t /= a.RH;
-    const int rd = (int)(t % a.RD); t /= a.RD;
+    unsigned t = (unsigned)m;
+    const int rw = (int)(t % (unsigned)a.RW); t /= (unsigned)a.RW;
+    const int rh = (int)(t % (unsigned)a.RH); t /= (unsigned)a.RH;
+    const int rd = (int)(t % (unsigned)a.RD); t /= (unsigned)a.RD;
     bf16_t* yrow = a.y + t * a.ysn + (long)(rd * a.os[0] + a.oo[0]) * a.ysd + (long)(rh * a.os[1] + a.oo[1]) * a.ysh +
                    (long)(rw * a.os[2] + a.oo[2]) * a.ysw;
     float bv[4];
@@ -461,6 +461,7 @@ static int launch_igemm4_any(const CL5& X, const CL5& Y, const void* w_packed, c
   a.cout = p->cout; a.cout_lanes = Y.lanes; a.wrows = round_up(p->cout, 16);
   a.act = p->act; a.slope = p->slope;
   a.M = (long)X.N * a.RD * a.RH * a.RW;
+  if (a.M >= (1L << 31)) RG_FAIL(RG_ERR_UNSUPPORTED, "conv: 2^31 output rows or more (the kernels decode rows with 32-bit divisions)");
   const int ntaps = a.TD * a.TH * a.TW;
   a.cp = X.lanes / 8;
   a.krow = round_up(ntaps * X.lanes, 64);

@@ -33,6 +33,13 @@ def train_step(model, loss_fn, optimizer, batch, grad_sync=None, scaler=None):
     if hasattr(optimizer, "zero_grad"):
         optimizer.zero_grad()
     own_step = not isinstance(optimizer, torch.optim.Optimizer)   # the CycleGAN losses own backward + step (LinkCycleLoss.py:87-135)
+    if hasattr(optimizer, "overlap_backward") and not own_step:
+        # this step is ONE backward followed by step(): FusedAdam may update every parameter as soon as its gradient exists, under the rest of the
+        # backward pass — unless the gradients are still to be checked (loss scaler) or averaged across ranks afterwards.  Opt-in
+        # (RAYGUN_AMD_ADAM_OVERLAP=1): on MI355X it buys nothing, the convolution kernels hold the whole register file
+        from ... import parallel
+        optimizer.overlap_backward(scaler is None and (grad_sync is None or parallel.world_size() == 1)
+                                   and os.environ.get("RAYGUN_AMD_ADAM_OVERLAP", "0") == "1")
     if scaler is not None and own_step:
         if not hasattr(loss_fn, "_backward"):
             raise RuntimeError("raygun_amd.train_step: loss scaling with a loss that owns backward() and step() needs raygun_amd's "

@@ -389,6 +389,48 @@ def test_fused_adam_refreshes_packed_forward_operand(cin, cout):
 
 
 @pytest.mark.gpu
+def test_fused_adam_under_the_backward_pass_is_bit_identical():
+    """FusedAdam.overlap_backward(): every update is enqueued from the parameter's post-accumulate-grad hook on a side stream (big tensors at once,
+    small ones collected) and step() is the join — parameters, moments, step counts and the refreshed packed operands after 3 steps must equal the
+    plain order bit for bit (same kernel, same arithmetic), including a parameter that gets no gradient and a second parameter group."""
+    from raygun_amd import hipnn
+    from raygun_amd.torch.optimizers import FusedAdam
+    dev = torch.device("cuda")
+
+    def make():
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(hipnn.Conv3d(4, 96, 3), torch.nn.ReLU(), hipnn.Conv3d(96, 160, 3), torch.nn.ReLU(), hipnn.Conv3d(160, 8, 1)).to(dev)
+        unused = torch.nn.Parameter(torch.ones(5, device=dev))
+        opt = FusedAdam([{"params": list(net[:4].parameters())}, {"params": list(net[4:].parameters()) + [unused], "lr": 3e-3}], lr=1e-2, weight_decay=1e-3)
+        return net, opt, unused
+    x = rnd((1, 4, 12, 12, 12), 21).to(dev)
+    nets = []
+    for overlap in (False, True):
+        net, opt, unused = make()
+        if overlap:
+            opt.overlap_backward(flush_numel=100000)     # the 96 -> 160 weight (414 720 elements) goes at once, the rest is collected
+        for it in range(3):
+            opt.zero_grad()
+            net(x).float().pow(2).mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        nets.append((net, opt, unused))
+    (na, oa, ua), (nb, ob, ub) = nets
+    assert torch.equal(ua, ub) and len(oa.state[ua]) == 0 and len(ob.state[ub]) == 0
+    for pa, pb in zip(na.parameters(), nb.parameters()):
+        assert torch.equal(pa, pb)
+        for k in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(oa.state[pa][k], ob.state[pb][k]), k
+        ca, cb = getattr(pa, "_rg_pack_cache", None), getattr(pb, "_rg_pack_cache", None)
+        if ca is not None and "fwd_pack" in ca:
+            assert cb is not None and cb["ver"] == (pb._version, pb.data_ptr())
+            assert torch.equal(ca["fwd_pack"][0].view(torch.int16), cb["fwd_pack"][0].view(torch.int16))
+    ob.overlap_backward(False)
+    ob.zero_grad(); nb(x).float().pow(2).mean().backward(); before = [p.detach().clone() for p in nb.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(before, nb.parameters())), "hooks removed: nothing moves before step()"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gs,fs,target", [((9, 9, 9), (20, 20, 20), (18, 18, 18)), ((9, 10, 11), (22, 21, 23), (16, 18, 20)),
                                            ((8, 9, 8), (16, 17, 15), (13, 15, 11)), ((10, 9, 9), (24, 18, 20), (15, 17, 13))])
 def test_upcat_conv3d_equals_upsample_crop_concat_conv(gs, fs, target):
