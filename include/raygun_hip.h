@@ -260,6 +260,12 @@ int rg_adam_step_pack(float* p, const float* g, float* m, float* v, int64_t n, f
 int rg_adam_step_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
                        const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                        float grad_scale, rg_stream s);
+/* the same with the step-dependent values in DEVICE memory: hyp = { lr, 1 - beta1^step, sqrt(1 - beta2^step) } (3 floats; NULL = rg_adam_step_multi) is
+ * read by the kernel, `lr` and `step` are ignored — a launch captured in a HIP graph (raygun_amd/graphs.py) stays correct as the step count advances
+ * (torch.optim.Adam(capturable=True) keeps its step on the device for the same reason). */
+int rg_adam_step_multi_hyp(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
+                           const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                           float grad_scale, const float* hyp, rg_stream s);
 
 /* ---- loss-scaled f16-storage training (no reference counterpart: the reference trains in fp32; torch.cuda.amp.GradScaler's
  * "unscale and look for inf" step without the unscale pass — rg_adam_step takes 1/scale as grad_scale).

@@ -101,6 +101,8 @@ _SIGS = {
                                C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p, _P(rg_pack_params), C.c_void_p]),
     "rg_adam_step_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "rg_adam_step_multi_hyp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "rg_lz4_decompress_block": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "rg_lz4_compress_bound": (C.c_int64, [C.c_int64]),
     "rg_lz4_compress_block": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),

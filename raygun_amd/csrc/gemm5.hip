@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
         for (int j = 0; j < FN; ++j) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(slot + (i * FN + j) * 2048), "v"(acc[i][j]) : "memory");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have been acknowledged
       __syncthreads();                                     // ... and everybody's
-      if (etid == 0) __hip_atomic_fetch_max(a.sk_flags + wg, a.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (etid == 0) __hip_atomic_store(a.sk_flags + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       finish = false;
     } else if (ku0 != 0) {
       // the tail of a tile others started: every workgroup below this one whose run reaches into the tile left ONE partial there, the piece it
@@ -305,7 +305,12 @@ __global__ __launch_bounds__(512, 1) void igemm5_kernel(Igemm4Args a) {
       for (int w2 = wg - 1; cov > tile_start && w2 >= 0; --w2) {
         const long s2 = sk_units * w2 / nwg;
         if (s2 == cov) continue;                           // (an empty run)
-        if (etid == 0) { while (__hip_atomic_load(a.sk_flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sk_epoch < 0) __builtin_amdgcn_s_sleep(4); }
+        if (etid == 0) {
+          while (__hip_atomic_load(a.sk_flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+          // every partial has exactly ONE reader: it lowers the flag again, so a launch leaves its row as it found it — zeros — and the same launch
+          // can be replayed from a captured graph (an epoch in the kernel arguments would be frozen into the graph)
+          __hip_atomic_store(a.sk_flags + w2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const float* slot = a.sk_part + (long)w2 * SLOT + etid * 4;
         // one accumulator row (FN loads in flight) at a time: the fragment registers are free here, more would spill
@@ -422,7 +427,8 @@ struct G5Plan { int fn; int ksplit; int sk; };
 // and the workgroup that started that tile adds the 1-2 partials before the ordinary epilogue: no combine pass, ~0.7 partials per tile instead of
 // `ksplit` whole copies.  rg_opt(RG_OPT_SK): 0 heuristic, 1 wherever the tiling allows, -1 off.
 #define G5_SK_GRID 256
-#define G5_SK_ROWS 64       // flag rows (launches in flight on different streams use different rows; a row comes round again 64 stream-K launches later)
+#define G5_SK_ROWS 64       // flag rows: consecutive launches take consecutive rows, so launches in flight on different streams do not share one
+                            // (a row comes round again 64 stream-K launches later; launches of one stream are ordered anyway)
 static size_t g5_sk_bytes(int fn) { return (size_t)G5_SK_GRID * 4 * fn * 512 * 16; }
 static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size_t ws_bytes, int cout_lanes, bool sk_ok = true) {
   G5Plan pl = {0, 1, 0};
@@ -474,7 +480,7 @@ size_t rg_igemm5_sk_bytes(const CL5& X, const CL5& Y, const rg_conv_params* p) {
 }
 void rg_launch_igemm4_combine(const Igemm4Args& a, hipStream_t st);   // conv4.hip: y = act(sum of the K-slices' partial tiles + bias)
 
-// per-device flag rows of the stream-K schedule, zeroed once; epochs only grow, so nothing ever resets them
+// per-device flag rows of the stream-K schedule, zeroed once; every launch lowers the flags it raised (the reader of a partial resets its flag)
 static int* g5_sk_flag_rows() {
   static std::mutex mu; static int* cache[64];
   int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -507,11 +513,11 @@ int rg_launch_igemm5(Igemm4Args& a, bool check, hipStream_t st, float* ws, size_
   });
   if (a.d2s_c && pl.ksplit > 1) { rg_set_error("igemm5: depth-to-space epilogue with split-K"); return RG_ERR_UNSUPPORTED; }
   if (pl.sk) {
-    static std::atomic<int> epoch{0};
+    static std::atomic<unsigned> launches{0};
     int* rows = g5_sk_flag_rows();
     if (!rows) { rg_set_error("igemm5: cannot allocate the stream-K flags"); return RG_ERR_HIP; }
-    const int e = epoch.fetch_add(1, std::memory_order_relaxed) + 1;
-    a.sk_grid = pl.sk; a.sk_part = ws; a.sk_epoch = e; a.sk_flags = rows + (size_t)((unsigned)e % G5_SK_ROWS) * G5_SK_GRID;
+    const unsigned e = launches.fetch_add(1, std::memory_order_relaxed);
+    a.sk_grid = pl.sk; a.sk_part = ws; a.sk_epoch = 0; a.sk_flags = rows + (size_t)(e % G5_SK_ROWS) * G5_SK_GRID;
     rg_set_kernel_name("igemm5_kernel<%d,%d>+streamK%s", (int)check, pl.fn, a.d2s_c ? "+d2s" : "");
     const dim3 grid((unsigned)pl.sk);
     if (pl.fn == 9) {

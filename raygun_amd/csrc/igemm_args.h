@@ -23,7 +23,7 @@ struct Igemm4Args {
   // batch b goes to raw + b * raw_batch + m * raw_ld + n (no bias / activation / 16-bit store); raw = nullptr: off
   long wld; int nbatch1; long wbatch2; float* raw; long raw_ld, raw_batch;
   // igemm5 only — stream-K (gemm5.hip): sk_grid > 0 workgroups share the (tile, K-tile) space in equal contiguous runs; a run that starts inside a
-  // tile leaves its fp32 partial in sk_part[workgroup] and raises sk_flags[workgroup] to sk_epoch, the workgroup that started the tile adds them
+  // tile leaves its fp32 partial in sk_part[workgroup] and raises sk_flags[workgroup]; the workgroup that finishes the tile adds them and lowers the flags again
   int sk_grid; float* sk_part; int* sk_flags; int sk_epoch;
   int d2s_c;  // igemm5 only, 0 = off: the columns are 8 parity classes x d2s_c channels of a sub-pixel (stride-2 transposed) convolution — column
               // c goes to channel c % d2s_c of output voxel 2 * row + parity(c / d2s_c) (depth-to-space in the epilogue; os = 2, bias per channel)

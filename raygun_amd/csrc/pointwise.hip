@@ -1199,7 +1199,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 #define ADAM_MT 24
 struct AdamItem { float* p; const float* g; float* m; float* v; long n; AdamPack pk; int vec; int blk0; };
 struct AdamTable { AdamItem it[ADAM_MT]; int n_items; int nblocks; };
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable T, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamTable T, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale, const float* hyp) {
+  if (hyp) { lr = hyp[0]; bc1 = hyp[1]; bc2_sqrt = hyp[2]; }   // the step-dependent values from device memory: a launch captured in a HIP graph stays valid
   int k = 0;
   while (k + 1 < T.n_items && (int)blockIdx.x >= T.it[k + 1].blk0) ++k;
   const AdamItem& I = T.it[k];
@@ -1235,7 +1236,15 @@ static int adam_pack_of(void* packed, const rg_pack_params* pp, int64_t n, AdamP
 extern "C" int rg_adam_step_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
                                   const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                                   float grad_scale, rg_stream s) {
-  if (n_items < 0 || step < 1 || (n_items && (!p || !g || !m || !v || !n))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_multi: bad arguments");
+  return rg_adam_step_multi_hyp(p, g, m, v, n, packed, pp, n_items, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, s);
+}
+// hyp (device, 3 floats, or NULL): { lr, 1 - beta1^step, sqrt(1 - beta2^step) } read BY THE KERNEL instead of the by-value lr / step — the caller keeps them
+// current on the device (FusedAdam(capturable=True)), so that the launch can be captured in a HIP graph and replayed step after step
+extern "C" int rg_adam_step_multi_hyp(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, void* const* packed,
+                                      const rg_pack_params* const* pp, int32_t n_items, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                      float grad_scale, const float* hyp, rg_stream s) {
+  if (n_items < 0 || (step < 1 && !hyp) || (n_items && (!p || !g || !m || !v || !n))) RG_FAIL(RG_ERR_BAD_SHAPE, "adam_multi: bad arguments");
+  if (step < 1) step = 1;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   int done = 0;
   while (done < n_items) {
@@ -1257,7 +1266,7 @@ extern "C" int rg_adam_step_multi(float* const* p, const float* const* g, float*
     }
     if (!T.n_items) break;
     T.nblocks = blocks;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, T, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, T, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, hyp);
     RG_CHECK_LAUNCH();
   }
   return RG_OK;

@@ -14,13 +14,62 @@ from ... import ops
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False):
         if amsgrad:
             raise NotImplementedError("raygun_amd.FusedAdam: amsgrad is not built")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.grad_scale = 1.0   # gradients are multiplied by this inside the kernel (amp.LossScaler sets 1 / loss scale around step())
         self._ov = None         # overlap_backward() state
+        # capturable (torch.optim.Adam's word for it): the step-dependent scalars — lr, 1 - beta1^t, sqrt(1 - beta2^t) — live in DEVICE memory and are advanced
+        # by device ops inside step(), so a step() captured in a HIP graph (raygun_amd/graphs.py) stays right on every replay.  All parameters of a group
+        # then share ONE step count (torch's capturable Adam keeps one per parameter; here it is one per group, the multi-tensor launch's granularity).
+        self.capturable = bool(capturable)
+        self._cap = {}          # id(group) -> {"t": float64[1] step count, "hyp": float32[3], "lr": the lr last written}
+
+    # ------------------------------------------------------------------------------------------------ device-side step scalars (capturable)
+    def _cap_state(self, group, device):
+        c = self._cap.get(id(group))
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("raygun_amd.FusedAdam(capturable=True): run at least one eager step before capturing (the device-side step state is "
+                                   "allocated on first use)")
+            t0 = max([float(self.state[p]["step"]) for p in group["params"] if p in self.state and len(self.state[p])] or [0.0])
+            c = {"t": torch.full((1,), t0, dtype=torch.float64, device=device), "hyp": torch.zeros(3, dtype=torch.float32, device=device), "lr": None,
+                 "b": torch.tensor(group["betas"], dtype=torch.float64, device=device)}
+            self._cap[id(group)] = c
+        return c
+
+    def _cap_advance(self, group, device):
+        """t += 1 and the two bias corrections, on the device (captured with the step when a graph is being recorded)."""
+        c = self._cap_state(group, device)
+        if c["lr"] != float(group["lr"]):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("raygun_amd.FusedAdam: the learning rate changed while a graph was being captured; call sync_hyper() before the capture")
+            c["hyp"][0:1].fill_(float(group["lr"])); c["lr"] = float(group["lr"])
+        c["t"].add_(1.0)
+        bc = 1.0 - torch.pow(c["b"], c["t"])           # float64: [1 - b1^t, 1 - b2^t]
+        c["hyp"][1:2].copy_(bc[0:1]); c["hyp"][2:3].copy_(torch.sqrt(bc[1:2]))
+        return c["hyp"]
+
+    def sync_hyper(self):
+        """Host -> device: learning rates a scheduler changed since the last step (call between graph replays; graphs.GraphedStep does)."""
+        for group in self.param_groups:
+            c = self._cap.get(id(group))
+            if c is not None and c["lr"] != float(group["lr"]):
+                c["hyp"][0:1].fill_(float(group["lr"])); c["lr"] = float(group["lr"])
+
+    def replayed(self):
+        """A captured step() has run once more on the device: advance the host-side step counts (state_dict fidelity) and the parameters' versions —
+        operands cached per version OTHER than the forward pack (backward-data packs, Winograd transforms) were computed inside the graph from the
+        weights before its update, so an eager call after the replay must not take them for current."""
+        for group in self.param_groups:
+            if id(group) in self._cap:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st is not None and len(st):
+                        st["step"] += 1
+                        torch.autograd.graph.increment_version(p)
 
     # ------------------------------------------------------------------------------------------------ one parameter -> one work item
     def _item(self, p):
@@ -47,7 +96,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _launch(self, group, step, items):
         b1, b2 = group["betas"]
-        fwds = ops.adam_step_multi_(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, float(self.grad_scale))
+        hyp = self._cap_advance(group, items[0][0].device) if self.capturable else None
+        fwds = ops.adam_step_multi_(items, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, float(self.grad_scale), hyp)
         for (p, _, _, _), fwd in zip(items, fwds):
             # the kernel wrote through the raw pointer: tell autograd (packed-weight caches key on _version)
             torch.autograd.graph.increment_version(p)
@@ -116,12 +166,16 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         ov = self._ov
         for group in self.param_groups:
+            if self.capturable and id(group) not in self._cap:      # (before this step's counts advance: the device count starts where the host's stands)
+                dev = next((p.device for p in group["params"] if p.is_cuda), None)
+                if dev is not None:
+                    self._cap_state(group, dev)
             batches = {}      # step count -> [(p, g, exp_avg, exp_avg_sq)]: one multi-tensor launch per 24 tensors that share the hyper-parameters
             for p in group["params"]:
                 if p.grad is None or (ov is not None and p in ov["done"]):
                     continue
                 item, step = self._item(p)
-                batches.setdefault(step, []).append(item)
+                batches.setdefault(0 if self.capturable else step, []).append(item)   # capturable: one step count per group (on the device)
             for step, items in batches.items():
                 self._launch(group, step, items)
         if ov is not None:

@@ -431,6 +431,48 @@ def test_fused_adam_under_the_backward_pass_is_bit_identical():
 
 
 @pytest.mark.gpu
+def test_graphed_step_replays_equal_eager_steps():
+    """raygun_amd.graphs.GraphedStep on a small deterministic network (convolutions incl. a forced stream-K launch, ReLU, an MSE-type loss, backward,
+    FusedAdam(capturable=True)): two eager warm-up steps, one captured, three replays, on inputs rewritten in place — parameters, moments and step
+    counts against the same six steps run eagerly with the ordinary optimiser.  The only arithmetic difference is the bias correction 1 - beta^t
+    (float64 on the device instead of powf on the host, a last-bit difference that six Adam steps carry into the 5th digit of the losses)."""
+    from raygun_amd import hipnn, ops
+    from raygun_amd.graphs import GraphedStep
+    from raygun_amd.torch.optimizers import FusedAdam
+    dev = torch.device("cuda")
+    xs = [rnd((1, 4, 14, 14, 14), 300 + i).to(dev) for i in range(6)]
+
+    def run(graphed):
+        torch.manual_seed(7)
+        net = torch.nn.Sequential(hipnn.Conv3d(4, 128, 3), torch.nn.ReLU(), hipnn.Conv3d(128, 256, 3), torch.nn.ReLU(), hipnn.Conv3d(256, 8, 1)).to(dev)
+        opt = FusedAdam(net.parameters(), lr=1e-3, betas=(0.8, 0.99), capturable=graphed)
+        x = torch.zeros_like(xs[0])
+
+        def body():
+            opt.zero_grad()
+            loss = net(x).float().pow(2).mean()
+            loss.backward()
+            opt.step()
+            return loss
+        gs = GraphedStep(body, optimizers=[opt], warmup=2) if graphed else None
+        losses = []
+        with ops.option("RG_GEMM5", 1), ops.option("RG_SK", 1):       # the 128 -> 256 layer runs igemm5 stream-K: flags lowered by their readers, replay after replay
+            for xi in xs:
+                x.copy_(xi)
+                losses.append(float(gs() if graphed else body()))
+        if graphed:
+            assert gs.graph is not None
+        return losses, [p.detach().clone() for p in net.parameters()], [opt.state[p] for p in net.parameters()]
+    la, pa, sa = run(False)
+    lb, pb, sb = run(True)
+    assert all(abs(a - b) <= 2e-4 * abs(a) for a, b in zip(la, lb)), (la, lb)
+    for a, b, ta, tb in zip(pa, pb, sa, sb):
+        assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max()))
+        assert float(ta["step"]) == float(tb["step"]) == 6.0
+        assert float((ta["exp_avg"] - tb["exp_avg"]).abs().max()) <= 1e-3 * max(1e-6, float(ta["exp_avg"].abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gs,fs,target", [((9, 9, 9), (20, 20, 20), (18, 18, 18)), ((9, 10, 11), (22, 21, 23), (16, 18, 20)),
                                            ((8, 9, 8), (16, 17, 15), (13, 15, 11)), ((10, 9, 9), (24, 18, 20), (15, 17, 13))])
 def test_upcat_conv3d_equals_upsample_crop_concat_conv(gs, fs, target):
