@@ -314,14 +314,14 @@ def test_link_step_at_full_size_128cube_properties():
 def test_graphed_step_equals_eager_steps():
     """raygun_amd.graphs.GraphedStep: the whole Link step — four generator passes, every backward, both optimiser steps — recorded in ONE HIP graph after
     two eager steps and replayed; six steps on changing inputs (written in place into the static input tensors) against six eager steps of a twin
-    system: the losses and parameters stay inside the spread of two EAGER runs (see below), Adam's host-side step counts follow the replays, and an
-    eager step AFTER the replays sees current operands (the versions of the parameters moved with the replays)."""
+    system with the same (capturable) optimisers: every loss_dict entry of every step and every parameter BIT-IDENTICAL, Adam's host-side step counts
+    follow the replays, and an eager step AFTER the replays sees current operands (the versions of the parameters moved with the replays)."""
     from raygun_amd.graphs import GraphedStep
     shape = (1, 1, 32, 32, 32)
     batches = [(synth.uniform(shape, 190 + 2 * it), synth.uniform(shape, 191 + 2 * it)) for it in range(7)]
 
-    def run(graphed):
-        s, dev = build_system("link", optim_extra={"capturable": True} if graphed else None)
+    def run(graphed, capturable):
+        s, dev = build_system("link", optim_extra={"capturable": True} if capturable else None)
         A, B = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
 
         def body():
@@ -345,18 +345,18 @@ def test_graphed_step_equals_eager_steps():
             assert gs.graph is not None and gs.calls == 6
         steps = sorted({int(st["step"]) for o in opts for st in o.state.values() if len(st)})
         return recs, [p.detach().float().cpu() for n in (s.netG1, s.netG2, s.netD1, s.netD2) for p in n.parameters()], steps
-    ra, pa, sa = run(False)
-    rb, pb, sb = run(True)
-    rc, pc, sc = run(False)
-    assert sa == sb == [7]
+    ra, pa, sa = run(False, False)     # the plain eager step
+    rc, pc, sc = run(False, True)      # eager, optimisers with device-side step scalars
+    rb, pb, sb = run(True, True)       # the same, captured after two steps and replayed
+    assert sa == sb == sc == [7]
+    # replay == eager, bit for bit: every kernel of the step is deterministic and the graph launches the same kernels on the same operands
+    for it, (d1, d2) in enumerate(zip(rc, rb)):
+        assert d1 == d2, (it, {k: (d1[k], d2[k]) for k in d1 if d1[k] != d2[k]})
+    assert all(torch.equal(a, b) for a, b in zip(pc, pb))
 
+    # against the plain optimiser the only arithmetic difference is the bias correction 1 - beta^t (float64 on the device instead of powf on the host);
+    # this tiny GAN amplifies a last-bit difference (Adam turns noise-level gradients into full +-lr steps, 16-bit operands round differently), so the
+    # comparison is loose — the tight one is tests/test_ops_gpu.py::test_graphed_step_replays_equal_eager_steps
     def dist(r1, r2):
         return max(abs(d1[k] - d2[k]) / max(1e-3, abs(d1[k])) for d1, d2 in zip(r1, r2) for k in d1)
-
-    def pdist(p1, p2):
-        num = sum(float((a - b).pow(2).sum()) for a, b in zip(p1, p2)); den = sum(float(a.pow(2).sum()) for a in p1)
-        return (num / den) ** 0.5
-    # two EAGER runs of this tiny GAN already differ (Adam turns noise-level gradients into full +-lr steps, and a few reductions of the step are not
-    # order-deterministic): the graphed run must sit inside that spread — the exact comparison is tests/test_ops_gpu.py::test_graphed_step_replays...
-    assert all(d1[k] == d2[k] for d1, d2 in zip(ra[:1], rb[:1]) for k in d1), "step 0 runs on identical weights"
-    assert dist(ra, rb) <= 3 * dist(ra, rc) + 2e-2 and pdist(pa, pb) <= 3 * pdist(pa, pc) + 1e-3, (dist(ra, rb), dist(ra, rc), pdist(pa, pb), pdist(pa, pc))
+    assert ra[0] == rc[0] and dist(ra, rc) <= 0.25

@@ -431,6 +431,30 @@ def test_fused_adam_under_the_backward_pass_is_bit_identical():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,stride,w", [(4, 2, 34), (7, 1, 20), (3, 2, 17)])
+def test_fold_w_taps_to_channels_and_its_deterministic_backward(kw, stride, w):
+    """ops._fold_w (the W taps of a one-channel input as channels: PatchGAN's first layer, the generator stems) against torch's as_strided on the CPU,
+    forward and input gradient (the overlap-add of the taps, in tap order, fp32); two backward passes give the same bits."""
+    from raygun_amd import ops
+    dev = torch.device("cuda")
+    x0 = bf(rnd((2, 1, 5, 6, w), 401))
+    wo = (w - kw) // stride + 1
+    xr = x0.clone().requires_grad_()
+    ref = torch.as_strided(xr, (2, kw, 5, 6, wo), (xr.stride(0), 1, xr.stride(2), xr.stride(3), stride), 0)
+    go = bf(rnd((2, kw, 5, 6, wo), 402))
+    (gr,) = torch.autograd.grad(ref, xr, go)
+    outs = []
+    for _ in range(2):
+        xd = x0.clone().to(dev).requires_grad_()
+        y = ops._fold_w(xd, kw, stride, (0, 0, 0))
+        assert tuple(y.shape) == (2, kw, 5, 6, wo) and torch.equal(y.float().cpu(), ref.detach())
+        (gx,) = torch.autograd.grad(y, xd, go.to(dev).to(y.dtype))
+        outs.append(gx.float().cpu())
+        assert float((outs[-1] - gr).abs().max()) <= 2 ** -7 * float(gr.abs().max())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
 def test_graphed_step_replays_equal_eager_steps():
     """raygun_amd.graphs.GraphedStep on a small deterministic network (convolutions incl. a forced stream-K launch, ReLU, an MSE-type loss, backward,
     FusedAdam(capturable=True)): two eager warm-up steps, one captured, three replays, on inputs rewritten in place — parameters, moments and step
