@@ -1167,10 +1167,13 @@ class _InstanceNorm(Function):
         ctx.save_for_backward(x, mr, y if act != "none" else None)
         ctx.cfg = (act, slope, res is not None)
         ctx.mark_non_differentiable(mr)
+        ctx.set_materialize_grads(False)   # (or autograd allocates and zero-fills a gradient for `mr` in front of every backward call: 100 launches per CycleGAN step)
         return y, mr
 
     @staticmethod
     def backward(ctx, gy, _gmr=None):
+        if gy is None:
+            return None, None, None, None, None
         x, mr, y = ctx.saved_tensors
         act, slope, has_res = ctx.cfg
         gy = as_cl(gy)
@@ -1245,10 +1248,13 @@ class _NormAffine(Function):
         if stats is None:
             stats = table.new_zeros(0)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
     def backward(ctx, gy, _gstats=None):
+        if gy is None:
+            return (None,) * 10
         x, table, gb, y = ctx.saved_tensors
         mode, act, slope, has_res, has_g, has_b = ctx.cfg
         gy = as_cl(gy)
