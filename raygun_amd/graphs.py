@@ -12,7 +12,11 @@ What capture needs from the step (and what GraphedStep checks or arranges):
   * kernels whose launch arguments do not encode "which launch this is": igemm5's stream-K flags are lowered by their reader, not compared with an epoch;
   * everything the library allocates for itself (stream-K flag rows, kernel attributes) exists before the capture: `warmup` eager steps come first.
 Data-parallel training stays eager (RCCL collectives are capturable, but the hooks' host-side bookkeeping is not replayed)."""
+import os
+
 import torch
+
+from . import _debug
 
 
 class GraphedStep:
@@ -24,6 +28,8 @@ class GraphedStep:
         self.fn, self.optimizers, self.warmup = fn, list(optimizers), int(warmup)
         self.graph, self.out, self.calls = None, None, 0
         self.stream = None
+        # the diagnostic modes wait for / copy back after every library call (guard bands, named synchronisation): nothing of that can sit in a capture
+        self.eager_only = bool(_debug.ON) or bool(os.environ.get("RAYGUN_AMD_DEBUG_SYNC"))
         for o in self.optimizers:
             if not getattr(o, "capturable", False):
                 raise RuntimeError("raygun_amd.GraphedStep: optimisers stepped inside a captured step must be FusedAdam(capturable=True)")
@@ -40,7 +46,7 @@ class GraphedStep:
         if self.stream is None:
             self.stream = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
-        if self.calls <= self.warmup:
+        if self.calls <= self.warmup or self.eager_only:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 out = self.fn()
