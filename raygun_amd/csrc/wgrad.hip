@@ -635,10 +635,19 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   bf16_t* Xs = lds + 2 * 32 * SA;     // [2][XR][SB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wt = wave / (WA * WB), wa = (wave / WB) % WA, wb = wave % WB;
-  const int a0 = (blockIdx.x / p.ntb) * TA, b0 = (blockIdx.x % p.ntb) * TB;
-  const int kh = blockIdx.y % a.TH, kd = blockIdx.y / a.TH;
+  // XCD-aware logical order (as wgrad_kwp_kernel): workgroups are dealt round-robin to the 8 XCDs, so consecutive blockIdx values — the nine (kd, kh) of
+  // one split, which read the same input lines — sat behind eight different L2s (rocprofv3 FETCH_SIZE: 3.0 GB per launch of the 84 -> 12 gradient, whose
+  // operands are 260 MB); each XCD now owns a contiguous run of (tile, (kd, kh), split) triples
+  int a0, b0, kh, kd, zsplit;
+  {
+    const int ny = gridDim.y, total = gridDim.x * ny * gridDim.z;
+    int lin = blockIdx.x + gridDim.x * (blockIdx.y + ny * blockIdx.z);
+    { const int q = total / 8, r = total % 8, xcd = lin % 8, idx = lin / 8; lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
+    const int t = lin % (int)gridDim.x; lin /= (int)gridDim.x; const int y = lin % ny; zsplit = lin / ny;
+    a0 = (t / p.ntb) * TA; b0 = (t % p.ntb) * TB; kh = y % a.TH; kd = y / a.TH;
+  }
   const int xrows = 32 + a.TW - 1;
-  const long ubeg = (long)blockIdx.z * p.units_per_split;
+  const long ubeg = (long)zsplit * p.units_per_split;
   long uend = ubeg + p.units_per_split; if (uend > p.units) uend = p.units;
   const int gsw2 = (int)a.gsw * 2, gsh2 = (int)a.gsh * 2, xsw2 = (int)a.xsw * 2;
 
@@ -773,7 +782,7 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   }
 
   const int ntaps = a.TD * a.TH * a.TW;
-  float* out = a.part + (long)blockIdx.z * a.A * ntaps * a.B;
+  float* out = a.part + (long)zsplit * a.A * ntaps * a.B;
 #pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int t = wt + tt * WT;
