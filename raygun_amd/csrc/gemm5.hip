@@ -450,14 +450,15 @@ static G5Plan g5_plan(long M, int wrows, int kunits, int nbatch, bool flat, size
   // runs of >= 16 K-tiles (a run pays a two-tile prologue) and tiles long enough that a partial is small next to the work it saves
   const bool sk_can = sk_room && (sko >= 1 || (kunits >= 16 && tiles * kunits >= (long)G5_SK_GRID * 16));
   // Measured on 256 -> 256 at 32^3 (MI355X, us): backward, 154 tiles — whole tiles 182, igemm4 (192-row tiles) 200, stream-K 150; forward, 128 tiles —
-  // whole tiles 168, 2 K-slices + combine 121, stream-K 137 (with exactly two pieces per tile the hand-over is the combine pass run by half the
-  // chip while the other half idles).  So: K-slices where they tile the chip exactly, stream-K for the grids between whole rounds.
+  // whole tiles 168, 2 K-slices + combine 121 -> 113 and stream-K 137 -> 106 once the epilogues were straight-line code (gemm5.hip's LDS-staged tile): with
+  // exactly two pieces per tile the hand-over is the combine pass run by half the chip, but it saves the combine launch and the slices' second fp32 copy.
+  // So: stream-K for every grid that is not (nearly) whole rounds; K-slices only for callers whose workspace holds nothing else.
   if (tiles >= 150 && round_fill(tiles) >= 0.70) {
     pl.fn = fn;
     if (sk_can && (sko >= 1 || (round_fill(tiles) < 0.75 && tiles <= 3 * 256))) pl.sk = G5_SK_GRID;
     return pl;
   }
-  if (sk_can && (sko >= 1 || tiles >= 150)) { pl.fn = fn; pl.sk = G5_SK_GRID; return pl; }
+  if (sk_can) { pl.fn = fn; pl.sk = G5_SK_GRID; return pl; }
   if (nbatch == 1 && tiles < 150 && kunits >= 32 && (cout_lanes & 3) == 0) {   // split K: whole rounds of one workgroup per CU
     long ks = 256 / tiles; if (ks > 8) ks = 8; if (ks > kunits / 16) ks = kunits / 16;
     if (ks >= 2 && tiles * ks >= 150 && (size_t)ks * M * cout_lanes * 4 <= ws_bytes) { pl.fn = fn; pl.ksplit = (int)ks; }
