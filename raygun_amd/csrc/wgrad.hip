@@ -618,7 +618,11 @@ static bool wgrad_lines_ok(const CL5& G, const CL5& X, const rg_conv_params* p, 
 // bounds check: out-of-range rows read as zero), and the unit -> (n, d, h, chunk) decode is incremental.
 struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks; int nta, ntb; int flat; unsigned pmagic; int dbg; };
 
-template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP>
+// KHL (1 or TH): how many kh taps ONE workgroup owns.  The thin tiles (16 channels on one side) issue 4 MFMAs per wave between two barriers and are bound by that
+// round trip, not by bytes; with KHL = 3 the G tile is staged once for three input lines and every barrier is followed by three times the MFMAs:
+// 72 -> 12 (<5,1>: the 16-lane side is X) 0.243 -> 0.148 ms.  84 -> 12 (<1,8>: the X tile is the 128-lane side, three of them are 60 KB of LDS = two workgroups
+// per CU) measured 0.46 -> 0.50 ms and keeps KHL = 1.
+template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP, int KHL = 1>
 __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
   const WgradArgs& a = p.w;
   constexpr int NT = WA * WB * WT * 64;
@@ -630,9 +634,9 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   constexpr int PER_G = (32 * CA + NT - 1) / NT, PER_X = (XR * CB + NT - 1) / NT;
   constexpr int IA = FA / WA, IB = FB / WB;
   static_assert(FA % WA == 0 && FB % WB == 0, "wave layout must divide the tile");
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (32 * SA + XR * SB)];
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (32 * SA + KHL * XR * SB)];
   bf16_t* Gs = lds;                   // [2][32][SA]
-  bf16_t* Xs = lds + 2 * 32 * SA;     // [2][XR][SB]
+  bf16_t* Xs = lds + 2 * 32 * SA;     // [2][KHL][XR][SB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wt = wave / (WA * WB), wa = (wave / WB) % WA, wb = wave % WB;
   // XCD-aware logical order (as wgrad_kwp_kernel): workgroups are dealt round-robin to the 8 XCDs, so consecutive blockIdx values — the nine (kd, kh) of
@@ -644,7 +648,8 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
     int lin = blockIdx.x + gridDim.x * (blockIdx.y + ny * blockIdx.z);
     { const int q = total / 8, r = total % 8, xcd = lin % 8, idx = lin / 8; lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; }
     const int t = lin % (int)gridDim.x; lin /= (int)gridDim.x; const int y = lin % ny; zsplit = lin / ny;
-    a0 = (t / p.ntb) * TA; b0 = (t % p.ntb) * TB; kh = y % a.TH; kd = y / a.TH;
+    a0 = (t / p.ntb) * TA; b0 = (t % p.ntb) * TB;
+    if (KHL > 1) { kh = 0; kd = y; } else { kh = y % a.TH; kd = y / a.TH; }   // (KHL > 1: TH == KHL, grid.y = TD)
   }
   const int xrows = 32 + a.TW - 1;
   const long ubeg = (long)zsplit * p.units_per_split;
@@ -669,13 +674,15 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
     xl[k] = exists ? row * SB + ch * 8 : -1;
     xv[k] = (exists && c < a.blanes) ? (unsigned)(row * xsw2 + c * 2) : WG_OOB;
   }
-  f32x4 acc[TPW][IA][IB];
+  f32x4 acc[KHL][TPW][IA][IB];
+#pragma unroll
+  for (int h = 0; h < KHL; ++h)
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int i = 0; i < IA; ++i)
 #pragma unroll
-      for (int j = 0; j < IB; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < IB; ++j) acc[h][t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // load cursor (wave-uniform): unit -> (n, rd, rh, wc); flat units have no rh
   const int rhe = p.flat ? 1 : a.RH;
@@ -686,25 +693,14 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
     crh = (int)(t % (unsigned)rhe); t /= (unsigned)rhe;
     crd = (int)(t % (unsigned)a.RD); cn = (int)(t / (unsigned)a.RD);
   }
-  struct Staged { u32x4 g[PER_G], x[PER_X]; };
+  struct Staged { u32x4 g[PER_G], x[KHL][PER_X]; };
   auto gload = [&](Staged& r) {  // loads the unit under the cursor, then advances the cursor
     const int w0 = cwc * 32;
     const int id = crd * a.rs[0] + a.tb[0] + kd * a.ts[0];
-    const bf16_t* gbase; const bf16_t* xbase; int nrecg, nrecx, gadd, xadd;
-    if (p.flat) {
-      const bool ok = (unsigned)id < (unsigned)a.ID;
-      gbase = a.g + cn * a.gsn + crd * a.gsd; nrecg = a.RH * gsh2; gadd = 0;
-      xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd : a.x; nrecx = ok ? a.IH * a.IW * xsw2 : 0;
-      xadd = ((a.tb[1] + kh) * a.IW + a.tb[2] + w0) * xsw2;
-    } else {
-      const int ih = crh * a.rs[1] + a.tb[1] + kh * a.ts[1];
-      const bool ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
-      gbase = a.g + cn * a.gsn + crd * a.gsd + crh * a.gsh; nrecg = a.RW * gsw2; gadd = w0 * gsw2;
-      xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd + (long)ih * a.xsh : a.x; nrecx = ok ? a.IW * xsw2 : 0;
-      xadd = (w0 + a.tb[2]) * xsw2;
-    }
+    const bf16_t* gbase; int nrecg, gadd;
+    if (p.flat) { gbase = a.g + cn * a.gsn + crd * a.gsd; nrecg = a.RH * gsh2; gadd = 0; }
+    else { gbase = a.g + cn * a.gsn + crd * a.gsd + crh * a.gsh; nrecg = a.RW * gsw2; gadd = w0 * gsw2; }
     const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, (short)0, nrecg, 0x00020000);
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, nrecx, 0x00020000);
 #pragma unroll
     for (int k = 0; k < PER_G; ++k) {
       unsigned vo = gv[k] + (unsigned)gadd;
@@ -715,14 +711,32 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
       r.g[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)vo, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < PER_X; ++k) r.x[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xv[k] + (unsigned)xadd), 0, 0);
+    for (int hh = 0; hh < KHL; ++hh) {
+      const int khh = kh + hh;
+      const bf16_t* xbase; int nrecx, xadd;
+      if (p.flat) {
+        const bool ok = (unsigned)id < (unsigned)a.ID;
+        xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd : a.x; nrecx = ok ? a.IH * a.IW * xsw2 : 0;
+        xadd = ((a.tb[1] + khh) * a.IW + a.tb[2] + w0) * xsw2;
+      } else {
+        const int ih = crh * a.rs[1] + a.tb[1] + khh * a.ts[1];
+        const bool ok = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH;
+        xbase = ok ? a.x + cn * a.xsn + (long)id * a.xsd + (long)ih * a.xsh : a.x; nrecx = ok ? a.IW * xsw2 : 0;
+        xadd = (w0 + a.tb[2]) * xsw2;
+      }
+      const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, (short)0, nrecx, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < PER_X; ++k) r.x[hh][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(xv[k] + (unsigned)xadd), 0, 0);
+    }
     if (++cwc == p.wchunks) { cwc = 0; if (++crh == rhe) { crh = 0; if (++crd == a.RD) { crd = 0; ++cn; } } }
   };
   auto lstore = [&](const Staged& r, int buf) {
 #pragma unroll
     for (int k = 0; k < PER_G; ++k) if (gl[k] >= 0) *(u32x4*)(Gs + buf * 32 * SA + gl[k]) = r.g[k];
 #pragma unroll
-    for (int k = 0; k < PER_X; ++k) if (xl[k] >= 0) *(u32x4*)(Xs + buf * XR * SB + xl[k]) = r.x[k];
+    for (int hh = 0; hh < KHL; ++hh)
+#pragma unroll
+      for (int k = 0; k < PER_X; ++k) if (xl[k] >= 0) *(u32x4*)(Xs + (buf * KHL + hh) * XR * SB + xl[k]) = r.x[hh][k];
   };
 
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
@@ -737,17 +751,19 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
       gf[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 #pragma unroll
+    for (int hh = 0; hh < KHL; ++hh)
+#pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
       const int t = wt + tt * WT;
       if (t < a.TW) {
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
-          const bf16_t* base = Xs + (buf * XR + t + 8 * fg + fq) * SB + (wb * IB + j) * 16 + 4 * fp;
+          const bf16_t* base = Xs + ((buf * KHL + hh) * XR + t + 8 * fg + fq) * SB + (wb * IB + j) * 16 + 4 * fp;
           bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base));
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64*)(base + 4 * SB));
           const bf16x8 xf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int i = 0; i < IA; ++i) acc[tt][i][j] = RG_MFMA16(gf[i], xf, acc[tt][i][j]);
+          for (int i = 0; i < IA; ++i) acc[hh][tt][i][j] = RG_MFMA16(gf[i], xf, acc[hh][tt][i][j]);
         }
       }
     }
@@ -784,10 +800,12 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
   const int ntaps = a.TD * a.TH * a.TW;
   float* out = a.part + (long)zsplit * a.A * ntaps * a.B;
 #pragma unroll
+  for (int hh = 0; hh < KHL; ++hh)
+#pragma unroll
   for (int tt = 0; tt < TPW; ++tt) {
     const int t = wt + tt * WT;
     if (t >= a.TW) continue;
-    const int tap = (kd * a.TH + kh) * a.TW + t;
+    const int tap = (kd * a.TH + kh + hh) * a.TW + t;
 #pragma unroll
     for (int i = 0; i < IA; ++i)
 #pragma unroll
@@ -796,7 +814,7 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int aa = a0 + (wa * IA + i) * 16 + fg * 4 + r;
-          if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[tt][i][j][r];
+          if (aa < a.A && bb < a.B) out[((long)aa * ntaps + tap) * a.B + bb] = acc[hh][tt][i][j][r];
         }
       }
   }
@@ -1078,7 +1096,8 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   KwGeom kg;
   if (const int kind = wgrad_kw_kind(G, X, p, *fa, *fb, &kg)) {  // wgrad_kw_kernel: split over 32-row units
     const long units = kg.units;
-    const long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
+    long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
+    if (kind == 8 && p->T[1] == 3) tl /= 3;   // one workgroup owns the three kh taps (KHL = 3): a third of the workgroups per split
     // workgroups aimed at: whole rounds of co-resident workgroups, rounded DOWN so that the grid never spills a few workgroups
     // into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815).
     // Kernels with several workgroups per CU: 768 (measured on the whole U-Net step, so that the partial-sum traffic and the
@@ -1271,6 +1290,7 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
     else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
     else if (kind == 7) hipLaunchKernelGGL((wgrad_kw_kernel<1, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
+    else if (kind == 8 && a.TH == 3) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true, 3>), dim3(grid.x, a.TD, ns), dim3(192), 0, st, ka);
     else if (kind == 8) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 9) hipLaunchKernelGGL((wgrad_kw_kernel<8, 4, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
     else hipLaunchKernelGGL((wgrad_kw_kernel<4, 8, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
