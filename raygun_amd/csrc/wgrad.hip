@@ -621,7 +621,7 @@ struct WgradKwArgs { WgradArgs w; long units; long units_per_split; int wchunks;
 // KHL (1 or TH): how many kh taps ONE workgroup owns.  The thin tiles (16 channels on one side) issue 4 MFMAs per wave between two barriers and are bound by that
 // round trip, not by bytes; with KHL = 3 the G tile is staged once for three input lines and every barrier is followed by three times the MFMAs:
 // 72 -> 12 (<5,1>: the 16-lane side is X) 0.243 -> 0.148 ms.  84 -> 12 (<1,8>: the X tile is the 128-lane side, three of them are 60 KB of LDS = two workgroups
-// per CU) measured 0.46 -> 0.50 ms and keeps KHL = 1.
+// per CU) measured 0.46 -> 0.50 ms; its 96-lane form <1,6> (45 KB) 0.456 -> 0.39 ms.
 template <int FA, int FB, int WA, int WB, int WT, int TWM, bool DEEP, int KHL = 1>
 __global__ __launch_bounds__(WA* WB* WT * 64) void wgrad_kw_kernel(WgradKwArgs p) {
   const WgradArgs& a = p.w;
@@ -1070,6 +1070,7 @@ static int wgrad_kw_kind(const CL5& G, const CL5& X, const rg_conv_params* p, in
     if (fa == 5 && fb == 8) return 6;
     if (fa == 1 && fb == 8) return 7;
     if (fa == 5 && fb == 1) return 8;
+    if (fa == 1 && fb == 6) return 11;
     if (fa == 8 && fb == 4) return 9;
     if (fa == 4 && fb == 8) return 10;
   }
@@ -1089,6 +1090,9 @@ static int pick_f(int lanes) {
 
 static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int* fa, int* fb, int* nsplit, long* rows_per_split) {
   *fa = pick_f(G.lanes); *fb = pick_f(X.lanes);
+  // 84 -> 12 (the decoder's first convolution at the top level): a 96-lane X tile instead of 128, so that THREE of them — one workgroup owns the three kh taps, as the
+  // <5,1> tile does — stay at 45 KB of LDS: 0.456 -> 0.39 ms (with 128-lane tiles the same scheme measured 0.50)
+  if (*fa == 1 && X.lanes > 80 && X.lanes <= 96 && p->T[1] == 3 && p->T[2] == 3) *fb = 6;
   const long M = (long)G.N * p->R[0] * p->R[1] * p->R[2];
   const int ntaps = p->T[0] * p->T[1] * p->T[2];
   long tiles = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * ntaps;
@@ -1097,7 +1101,7 @@ static void wgrad_plan(const CL5& G, const CL5& X, const rg_conv_params* p, int*
   if (const int kind = wgrad_kw_kind(G, X, p, *fa, *fb, &kg)) {  // wgrad_kw_kernel: split over 32-row units
     const long units = kg.units;
     long tl = (long)((G.C + *fa * 16 - 1) / (*fa * 16)) * ((X.C + *fb * 16 - 1) / (*fb * 16)) * p->T[0] * p->T[1];
-    if (kind == 8 && p->T[1] == 3) tl /= 3;   // one workgroup owns the three kh taps (KHL = 3): a third of the workgroups per split
+    if ((kind == 8 || kind == 11) && p->T[1] == 3) tl /= 3;   // one workgroup owns the three kh taps (KHL = 3): a third of the workgroups per split
     // workgroups aimed at: whole rounds of co-resident workgroups, rounded DOWN so that the grid never spills a few workgroups
     // into an extra round (256 -> 256 at 32^3: 36 tiles x 22 splits = 792 = 3.1 rounds ran at 668 TFLOP/s, x 21 = 756 at 815).
     // Kernels with several workgroups per CU: 768 (measured on the whole U-Net step, so that the partial-sum traffic and the
@@ -1290,6 +1294,7 @@ extern "C" int rg_conv3d_wgrad2(const rg_tensor* g, const rg_tensor* x, float* d
     else if (kind == 5) hipLaunchKernelGGL((wgrad_kw_kernel<9, 5, 3, 1, 3, 3, true>), grid, dim3(576), 0, st, ka);
     else if (kind == 6) hipLaunchKernelGGL((wgrad_kw_kernel<5, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
     else if (kind == 7) hipLaunchKernelGGL((wgrad_kw_kernel<1, 8, 1, 2, 3, 3, true>), grid, dim3(384), 0, st, ka);
+    else if (kind == 11) hipLaunchKernelGGL((wgrad_kw_kernel<1, 6, 1, 2, 3, 3, true, 3>), dim3(grid.x, a.TD, ns), dim3(384), 0, st, ka);
     else if (kind == 8 && a.TH == 3) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true, 3>), dim3(grid.x, a.TD, ns), dim3(192), 0, st, ka);
     else if (kind == 8) hipLaunchKernelGGL((wgrad_kw_kernel<5, 1, 1, 1, 3, 3, true>), grid, dim3(192), 0, st, ka);
     else if (kind == 9) hipLaunchKernelGGL((wgrad_kw_kernel<8, 4, 2, 2, 1, 4, true>), grid, dim3(256), 0, st, ka);
